@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric: megapixels/s of the filter chain
+(gray -> Gaussian 5x5 -> median 3x3 -> Sobel) on 3840x2160 RGBA u8 frames, device-resident.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A step is one pass of the chain over one batch of B synthetic frames per GPU (inputs already in
+HBM).  N>1 is launched by torch.distributed.run, one process per GPU; frames are independent, so
+ranks share nothing on the data path (batch sharding, weak scaling) and RCCL is used only for
+the barrier and the max-over-ranks time.  Rank 0 prints one JSON line.
+
+Extra objects in the line:
+  roofline      the slowest of the four kernels: algorithmic bytes (8 B/pixel: 4 read + 4
+                written) per launch / its average launch duration, measured with
+                HIP events on the launch stream inside the timed region, against 8 TB/s.
+  cpu_baseline  the CPU oracle (a scalar C port of the reference's arithmetic) timed on this
+                host on a bounded sample of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 3840, 2160
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_PIXEL = 8.0           # algorithmic: 4 read + 4 written per u8x4 -> u8x4 filter
+STAGES = ["grayscale", "gaussian5", "median3", "sobel"]
+KERNELS = {"grayscale": "gray_kernel", "gaussian5": "gauss_sep_kernel<2>", "median3": "median3_kernel",
+           "sobel": "sobel_kernel"}
+
+
+def cpu_baseline(frames=1, threads=1):
+    """Oracle chain on `frames` synthetic 3840x2160 frames (checker code used as the baseline)."""
+    from oracle import golden
+    imgs = [golden.synth(2, W, H, first_idx=f * W * H) for f in range(frames)]
+    t0 = time.perf_counter()
+    for img in imgs:
+        golden.chain(img, threads=threads)
+    dt = time.perf_counter() - t0
+    return frames * W * H / 1e6 / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="3840x2160 frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from cudaimageprocessing_amd import ops
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    # frames [rank*B, (rank+1)*B) of the synthetic stream with seed 2
+    frames = ops.synth(2, W, H, batch=B, first_idx=rank * B * W * H, device=dev)
+    bufs = [torch.empty_like(frames) for _ in range(4)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(events=None):
+        stream = torch.cuda.current_stream()
+        if events is not None:
+            events[0].record(stream)
+        ops.grayscale(frames, bufs[0])
+        if events is not None:
+            events[1].record(stream)
+        ops.gaussian_blur(bufs[0], 5, 1.0, bufs[1])
+        if events is not None:
+            events[2].record(stream)
+        ops.median_blur(bufs[1], 3, bufs[2])
+        if events is not None:
+            events[3].record(stream)
+        ops.sobel(bufs[2], bufs[3])
+        if events is not None:
+            events[4].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel launch durations (ms) from the events recorded inside the timed region
+    per_stage = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
+                 for i in range(4)]
+
+    if rank == 0:
+        px_per_launch = B * W * H
+        mp_total = world * B * W * H / 1e6 * args.steps
+        worst = max(range(4), key=lambda i: per_stage[i])
+        achieved = px_per_launch * BYTES_PER_PIXEL / (per_stage[worst] * 1e-3) / 1e9
+        out = {
+            "metric": "megapixels/sec, full filter chain (gray, Gaussian 5x5, median 3x3, Sobel)",
+            "value": mp_total / elapsed,
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (fp32 accumulate in grayscale/Gaussian)",
+            "data": "synthetic",
+            "config": {"workload": f"C2 chain gray->gauss5(sigma 1.0)->median3->sobel, {W}x{H} RGBA u8, "
+                                   f"batch {B} frames per GPU, device-resident, 4 kernels per step",
+                       "frames_per_gpu": B, "width": W, "height": H, "sharding": f"batch x{world}"},
+            "per_filter": {STAGES[i]: {"ms": per_stage[i],
+                                       "MP/s": px_per_launch / 1e6 / (per_stage[i] * 1e-3),
+                                       "GB/s": px_per_launch * BYTES_PER_PIXEL / (per_stage[i] * 1e-3) / 1e9,
+                                       "roofline_frac": px_per_launch * BYTES_PER_PIXEL / (per_stage[i] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                           for i in range(4)},
+            "roofline": {"kernel": KERNELS[STAGES[worst]], "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": px_per_launch * BYTES_PER_PIXEL,
+                         "avg_launch_ms": per_stage[worst]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            v, dt = cpu_baseline(frames=1, threads=1)
+            out["cpu_baseline"] = {"value": v, "unit": "MP/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same 4-stage chain on 1 synthetic {W}x{H} frame, "
+                                             f"oracle/golden.c single thread, {dt:.1f} s"}
+            nthr = min(16, os.cpu_count() or 1)
+            v2, dt2 = cpu_baseline(frames=2, threads=nthr)
+            out["cpu_baseline_threads"] = {"value": v2, "unit": "MP/s", "cores": nthr, "kind": "port",
+                                           "sample": f"2 frames, row bands on {nthr} threads, {dt2:.1f} s"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

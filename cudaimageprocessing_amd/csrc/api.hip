@@ -1,0 +1,443 @@
+// api.hip -- the extern "C" surface of libmi_imagetools (include/mi_imagetools.h): argument
+// validation, error reporting, the blocking host tier and the PNG writer.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "internal.h"
+
+namespace mi {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_status(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return MI_OK;
+    snprintf(g_err, sizeof g_err, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return (int)e;
+}
+
+// generateGaussianKernal, reference kernels/imageTools.cu:362-385: expf of a float argument,
+// division by the double 2*pi*sigma^2, narrowed to float, summed in float in i-major order,
+// every entry divided by the sum.
+void gaussian_kernel_2d(int k, float sigma, float* out)
+{
+    float sum = 0.0f;
+    const int half = k / 2;
+    for (int i = -half; i <= half; i++)
+        for (int j = -half; j <= half; j++) {
+            const float e = expf((float)(-(i * i + j * j)) / (2 * sigma * sigma));
+            const float value = (float)((double)e / (2 * M_PI * (double)sigma * (double)sigma));
+            out[(i + half) * k + (j + half)] = value;
+            sum += value;
+        }
+    for (int i = 0; i < k * k; i++) out[i] /= sum;
+}
+
+// 1-D factor of the kernel above: w[i] = e_i / sum(e), evaluated in double and rounded once.
+void gaussian_kernel_1d(int k, float sigma, float* out)
+{
+    const int half = k / 2;
+    double e[MI_MAX_KERNEL_SIZE], sum = 0.0;
+    for (int i = -half; i <= half; i++) {
+        e[i + half] = exp(-(double)(i * i) / (2.0 * (double)sigma * (double)sigma));
+        sum += e[i + half];
+    }
+    for (int i = 0; i < k; i++) out[i] = (float)(e[i] / sum);
+}
+
+static bool overlap(const void* a, size_t na, const void* b, size_t nb)
+{
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
+static int check_image(const void* in, const void* out, int w, int h, int batch)
+{
+    if (!in || !out) return fail(MI_ERR_INVALID_ARG, "null image pointer");
+    if (w <= 0 || h <= 0 || batch <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive size %dx%d batch %d", w, h, batch);
+    if ((int64_t)w * h > (int64_t)1 << 40) return fail(MI_ERR_INVALID_ARG, "image too large");
+    return MI_OK;
+}
+
+static int check_filter(int filter, int w, int h, int ksize, float sigma)
+{
+    if (filter == MI_FILTER_GRAYSCALE) return MI_OK;
+    if (w < 3 || h < 3) return fail(MI_ERR_INVALID_ARG, "stencil filters need w>=3 and h>=3 (got %dx%d)", w, h);
+    switch (filter) {
+    case MI_FILTER_SOBEL: return MI_OK;
+    case MI_FILTER_GAUSSIAN:
+    case MI_FILTER_GAUSSIAN_DIRECT:
+        if (ksize < 1 || ksize % 2 == 0 || ksize > 15)
+            return fail(MI_ERR_BAD_KERNEL_SIZE, "Gaussian kernel size must be odd, in [1,15] (got %d)", ksize);
+        if (!(sigma > 0.0f) || !isfinite(sigma)) return fail(MI_ERR_INVALID_ARG, "sigma must be positive and finite");
+        return MI_OK;
+    case MI_FILTER_MEAN:
+        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE)
+            return fail(MI_ERR_BAD_KERNEL_SIZE, "mean kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, ksize);
+        return MI_OK;
+    case MI_FILTER_MEDIAN:
+        if (ksize != 3 && ksize != 5) return fail(MI_ERR_BAD_KERNEL_SIZE, "median kernel size must be 3 or 5 (got %d)", ksize);
+        return MI_OK;
+    default: return fail(MI_ERR_INVALID_ARG, "unknown filter %d", filter);
+    }
+}
+
+static int run_frames(int filter, const void* in, void* out, int w, int h, int batch, int ksize,
+                      float sigma, void* stream)
+{
+    int rc = check_image(in, out, w, h, batch);
+    if (rc) return rc;
+    rc = check_filter(filter, w, h, ksize, sigma);
+    if (rc) return rc;
+    const size_t bytes = (size_t)w * h * 4 * batch;
+    if (overlap(in, bytes, out, bytes)) return fail(MI_ERR_OVERLAP, "device-tier in/out buffers overlap");
+    // kernel size 1 is the identity on the write set; the generic paths handle it
+    FilterArgs a;
+    a.filter = filter;
+    if (filter == MI_FILTER_GAUSSIAN && ksize == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    a.in = in; a.out = out; a.w = w; a.h_total = h; a.batch = batch;
+    a.in_row0 = 0; a.in_rows = h; a.y_begin = 0; a.y_end = h;
+    a.ksize = ksize; a.sigma = sigma; a.stream = (hipStream_t)stream;
+    return launch_filter(a);
+}
+
+// Host tier: the reference wrapper's shape (kernels/imageTools.cu:233-253): device buffers,
+// H2D, kernel, D2H, free -- on one stream, blocking until `out` holds the result.
+static int run_host(int filter, const uint8_t* in, uint8_t* out, int w, int h, int ksize, float sigma)
+{
+    int rc = check_image(in, out, w, h, 1);
+    if (rc) return rc;
+    rc = check_filter(filter, w, h, ksize, sigma);
+    if (rc) return rc;
+    const size_t bytes = (size_t)w * h * 4;
+    void *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_in, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_out, bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = run_frames(filter, d_in, d_out, w, h, 1, ksize, sigma, nullptr);
+        if (rc == MI_OK) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    return hip_status(e, "host-tier filter");
+}
+
+// ---------------------------------------------------------------- PNG (RGBA8, zlib deflate)
+static void put_be32(std::vector<uint8_t>& v, uint32_t x)
+{
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+
+static void png_chunk(std::vector<uint8_t>& png, const char* tag, const uint8_t* data, size_t n)
+{
+    put_be32(png, (uint32_t)n);
+    const size_t start = png.size();
+    png.insert(png.end(), tag, tag + 4);
+    if (n) png.insert(png.end(), data, data + n);
+    put_be32(png, (uint32_t)crc32(0L, png.data() + start, (uInt)(n + 4)));
+}
+
+static int write_png_rgba(const char* filename, const uint8_t* px, int w, int h)
+{
+    const size_t pitch = (size_t)w * 4;
+    std::vector<uint8_t> raw((pitch + 1) * h);
+    for (int y = 0; y < h; y++) {
+        raw[(pitch + 1) * y] = 0;  // filter type None
+        memcpy(&raw[(pitch + 1) * y + 1], px + pitch * y, pitch);
+    }
+    uLongf zn = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK)
+        return fail(MI_ERR_IO, "zlib compress failed");
+    std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(png, "IHDR", ihdr.data(), ihdr.size());
+    png_chunk(png, "IDAT", z.data(), zn);
+    png_chunk(png, "IEND", nullptr, 0);
+    FILE* f = fopen(filename, "wb");
+    if (!f) return fail(MI_ERR_IO, "cannot open %s for writing", filename);
+    const bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
+    fclose(f);
+    return ok ? MI_OK : fail(MI_ERR_IO, "short write to %s", filename);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_version(void) { return 100; }
+const char* mi_last_error(void) { return g_err; }
+
+int mi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+// ---------------------------------------------------------------- device tier
+int mi_image_load_dev(const void* d_bytes, void* d_pixels, size_t n_pixels, void* stream)
+{
+    if (!d_bytes || !d_pixels) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (overlap(d_bytes, n_pixels * 4, d_pixels, n_pixels * 4)) return fail(MI_ERR_OVERLAP, "buffers overlap");
+    return launch_copy(d_bytes, d_pixels, n_pixels * 4, (hipStream_t)stream);
+}
+
+int mi_image_write_dev(void* d_bytes, const void* d_pixels, int w, int h, void* stream)
+{
+    if (!d_bytes || !d_pixels || w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
+    const size_t n = (size_t)w * h * 4;
+    if (overlap(d_bytes, n, d_pixels, n)) return fail(MI_ERR_OVERLAP, "buffers overlap");
+    return launch_copy(d_pixels, d_bytes, n, (hipStream_t)stream);
+}
+
+int mi_grayscale_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, void* stream)
+{
+    return run_frames(MI_FILTER_GRAYSCALE, d_in, d_out, w, h, batch, 0, 0.f, stream);
+}
+
+int mi_sobel_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, void* stream)
+{
+    return run_frames(MI_FILTER_SOBEL, d_in, d_out, w, h, batch, 3, 0.f, stream);
+}
+
+int mi_gaussian_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, int kernel_size,
+                         float sigma, int mode, void* stream)
+{
+    if (mode != MI_GAUSS_SEPARABLE && mode != MI_GAUSS_DIRECT) return fail(MI_ERR_INVALID_ARG, "unknown Gaussian mode %d", mode);
+    return run_frames(mode == MI_GAUSS_DIRECT ? MI_FILTER_GAUSSIAN_DIRECT : MI_FILTER_GAUSSIAN, d_in,
+                      d_out, w, h, batch, kernel_size, sigma, stream);
+}
+
+int mi_meanblur_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, int kernel_size, void* stream)
+{
+    return run_frames(MI_FILTER_MEAN, d_in, d_out, w, h, batch, kernel_size, 0.f, stream);
+}
+
+int mi_medianblur_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, int kernel_size, void* stream)
+{
+    return run_frames(MI_FILTER_MEDIAN, d_in, d_out, w, h, batch, kernel_size, 0.f, stream);
+}
+
+int mi_filter_halo_rows(int filter, int param_i) { return filter_halo_rows(filter, param_i); }
+
+int mi_filter_strip_u8x4_dev(int filter, const void* d_in, void* d_out, int w, int h_total,
+                             int in_row0, int in_rows, int y_begin, int y_end, int param_i,
+                             float param_f, void* stream)
+{
+    int rc = check_image(d_in, d_out, w, h_total, 1);
+    if (rc) return rc;
+    rc = check_filter(filter, w, h_total, param_i, param_f);
+    if (rc) return rc;
+    if (y_begin < 0 || y_end > h_total || y_begin >= y_end || in_rows <= 0)
+        return fail(MI_ERR_INVALID_ARG, "bad row range [%d,%d) of %d", y_begin, y_end, h_total);
+    const int halo = filter_halo_rows(filter, param_i);
+    const int need0 = std::max(0, y_begin - halo), need1 = std::min(h_total, y_end + halo);
+    if (in_row0 < 0 || in_row0 > need0 || in_row0 + in_rows < need1 || in_row0 + in_rows > h_total)
+        return fail(MI_ERR_INVALID_ARG, "input rows [%d,%d) do not cover the needed rows [%d,%d)",
+                    in_row0, in_row0 + in_rows, need0, need1);
+    if (overlap(d_in, (size_t)in_rows * w * 4, d_out, (size_t)(y_end - y_begin) * w * 4))
+        return fail(MI_ERR_OVERLAP, "device-tier in/out buffers overlap");
+    FilterArgs a;
+    a.filter = filter;
+    if (filter == MI_FILTER_GAUSSIAN && param_i == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    a.in = d_in; a.out = d_out; a.w = w; a.h_total = h_total; a.batch = 1;
+    a.in_row0 = in_row0; a.in_rows = in_rows; a.y_begin = y_begin; a.y_end = y_end;
+    a.ksize = param_i; a.sigma = param_f; a.stream = (hipStream_t)stream;
+    return launch_filter(a);
+}
+
+int mi_synth_u8x4_dev(void* d_out, uint64_t seed, uint64_t first_idx, uint64_t count, void* stream)
+{
+    if (!d_out) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    return launch_synth(d_out, seed, first_idx, count, (hipStream_t)stream);
+}
+
+int mi_debug_sobel_mag_table_dev(void* d_out_u8, uint32_t count, void* stream)
+{
+    if (!d_out_u8) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    return launch_sobel_table(d_out_u8, count, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- FFT path, device tier
+static int check_plane(const void* p, int w, int h)
+{
+    if (!p) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive size %dx%d", w, h);
+    return MI_OK;
+}
+
+int mi_u8_to_complex_dev(const void* d_in, void* d_red, void* d_green, void* d_blue, int w, int h, void* stream)
+{
+    if (!d_red || !d_green || !d_blue) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    int rc = check_plane(d_in, w, h);
+    if (rc) return rc;
+    return launch_u8_to_complex(d_in, d_red, d_green, d_blue, w, h, (hipStream_t)stream);
+}
+
+int mi_fft2d_c2c_f32_dev(const void* d_in, void* d_out, int rows, int cols, int batch, int direction, void* stream)
+{
+    if (!d_in || !d_out) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (batch <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive batch");
+    if (direction != MI_FFT_FORWARD && direction != MI_FFT_INVERSE) return fail(MI_ERR_INVALID_ARG, "direction must be -1 or +1");
+    auto pow2 = [](int n) { return n >= 2 && n <= 8192 && (n & (n - 1)) == 0; };
+    if (!pow2(rows) || !pow2(cols)) return fail(MI_ERR_UNSUPPORTED, "fft2d needs power-of-two sizes in [2,8192] (got %dx%d)", rows, cols);
+    const size_t bytes = (size_t)rows * cols * 8 * batch;
+    if (d_in != d_out && overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping buffers");
+    return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream);
+}
+
+int mi_fftshift_dev(void* d_data, int w, int h, void* stream)
+{
+    int rc = check_plane(d_data, w, h);
+    return rc ? rc : launch_fftshift(d_data, w, h, (hipStream_t)stream);
+}
+
+int mi_highpass_dev(void* d_data, int w, int h, float cutoff, void* stream)
+{
+    int rc = check_plane(d_data, w, h);
+    if (rc) return rc;
+    if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
+    return launch_highpass(d_data, w, h, cutoff, (hipStream_t)stream);
+}
+
+int mi_normalize_zero_imag_dev(void* d_data, int w, int h, void* stream)
+{
+    int rc = check_plane(d_data, w, h);
+    return rc ? rc : launch_normalize_zero_imag(d_data, w, h, (hipStream_t)stream);
+}
+
+int mi_complex_to_u8_dev(const void* d_red, const void* d_green, const void* d_blue, void* d_out, int w, int h, void* stream)
+{
+    if (!d_red || !d_green || !d_blue) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    int rc = check_plane(d_out, w, h);
+    return rc ? rc : launch_complex_to_u8(d_red, d_green, d_blue, d_out, w, h, (hipStream_t)stream);
+}
+
+int mi_minmax_f32_dev(const void* d_img, size_t n, void* d_minmax, void* stream)
+{
+    if (!d_img || !d_minmax || n == 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
+    return launch_minmax(d_img, n, d_minmax, (hipStream_t)stream);
+}
+
+int mi_normalize_to_u8_dev(const void* d_img, void* d_out, size_t n, const void* d_minmax, void* stream)
+{
+    if (!d_img || !d_out || !d_minmax || n == 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
+    return launch_normalize_to_u8(d_img, d_out, n, d_minmax, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- host tier
+int mi_image_load(const uint8_t* bytes, uint8_t* pixels, size_t n_pixels)
+{
+    if (!bytes || !pixels) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (n_pixels == 0) return MI_OK;
+    const size_t n = n_pixels * 4;
+    void *d_a = nullptr, *d_b = nullptr;
+    int rc = MI_OK;
+    hipError_t e = hipMalloc(&d_a, n);
+    if (e == hipSuccess) e = hipMalloc(&d_b, n);
+    if (e == hipSuccess) e = hipMemcpy(d_a, bytes, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = launch_copy(d_a, d_b, n, nullptr);
+        if (rc == MI_OK) e = hipMemcpy(pixels, d_b, n, hipMemcpyDeviceToHost);
+    }
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    return rc ? rc : hip_status(e, "mi_image_load");
+}
+
+int mi_image_write(const char* filename, const uint8_t* pixels, int w, int h)
+{
+    if (!filename || !pixels || w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
+    // The reference round-trips the pixels through the device (imageWrite kernel, a copy) before
+    // encoding; the bytes are identical, so the encoder reads the caller's buffer directly.
+    return write_png_rgba(filename, pixels, w, h);
+}
+
+int mi_grayscale_u8x4(const uint8_t* in, uint8_t* out, int w, int h)
+{
+    return run_host(MI_FILTER_GRAYSCALE, in, out, w, h, 0, 0.f);
+}
+
+int mi_sobel_u8x4(const uint8_t* in, uint8_t* out, int w, int h)
+{
+    return run_host(MI_FILTER_SOBEL, in, out, w, h, 3, 0.f);
+}
+
+int mi_gaussian_u8x4(const uint8_t* in, uint8_t* out, int w, int h, int kernel_size, float sigma, int mode)
+{
+    if (mode != MI_GAUSS_SEPARABLE && mode != MI_GAUSS_DIRECT) return fail(MI_ERR_INVALID_ARG, "unknown Gaussian mode %d", mode);
+    return run_host(mode == MI_GAUSS_DIRECT ? MI_FILTER_GAUSSIAN_DIRECT : MI_FILTER_GAUSSIAN, in, out, w, h, kernel_size, sigma);
+}
+
+int mi_meanblur_u8x4(const uint8_t* in, uint8_t* out, int w, int h, int kernel_size)
+{
+    return run_host(MI_FILTER_MEAN, in, out, w, h, kernel_size, 0.f);
+}
+
+int mi_medianblur_u8x4(const uint8_t* in, uint8_t* out, int w, int h, int kernel_size)
+{
+    return run_host(MI_FILTER_MEDIAN, in, out, w, h, kernel_size, 0.f);
+}
+
+int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)
+{
+    int rc = check_image(in, out, w, h, 1);
+    if (rc) return rc;
+    const size_t n = (size_t)w * h;
+    void* d_img = nullptr;
+    void* pl[3] = {nullptr, nullptr, nullptr};
+    hipError_t e = hipMalloc(&d_img, n * 4);
+    for (int c = 0; c < 3 && e == hipSuccess; c++) e = hipMalloc(&pl[c], n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = mi_u8_to_complex_dev(d_img, pl[0], pl[1], pl[2], w, h, nullptr);
+        for (int c = 0; c < 3 && rc == MI_OK; c++) {
+            rc = mi_fft2d_c2c_f32_dev(pl[c], pl[c], h, w, 1, MI_FFT_FORWARD, nullptr);
+            if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
+            if (rc == MI_OK) rc = mi_highpass_dev(pl[c], w, h, cutoff, nullptr);
+            if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
+            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_dev(pl[c], pl[c], h, w, 1, MI_FFT_INVERSE, nullptr);
+            if (rc == MI_OK) rc = mi_normalize_zero_imag_dev(pl[c], w, h, nullptr);
+        }
+        if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl[0], pl[1], pl[2], d_img, w, h, nullptr);
+        if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
+    }
+    if (d_img) (void)hipFree(d_img);
+    for (int c = 0; c < 3; c++) if (pl[c]) (void)hipFree(pl[c]);
+    return rc ? rc : hip_status(e, "mi_fft_highpass_u8x4");
+}
+
+int mi_gaussian_kernel(int kernel_size, float sigma, float* out)
+{
+    if (!out) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (kernel_size < 1 || kernel_size % 2 == 0 || kernel_size > MI_MAX_KERNEL_SIZE)
+        return fail(MI_ERR_BAD_KERNEL_SIZE, "kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, kernel_size);
+    if (!(sigma > 0.0f) || !isfinite(sigma)) return fail(MI_ERR_INVALID_ARG, "sigma must be positive and finite");
+    gaussian_kernel_2d(kernel_size, sigma, out);
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// common.h -- shared device helpers for the gfx950 image-filter kernels.
+//
+// Execution scheme of the 2-D stencil kernels ("wave march"): one 64-lane wave owns a column
+// strip of 64*4 pixels and marches down a band of rows.  Every lane holds 4 adjacent pixels
+// (one 16-byte load per row), keeps the rows of the stencil window in registers, and gets its
+// left/right neighbours' pixels from the adjacent lanes with DPP wave shifts -- no LDS, no
+// barriers.  The outermost M lanes on each side of a wave only feed their neighbours (their
+// own outputs are produced by the adjacent strip), so strips overlap by 2*M lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned int u32;
+typedef long long i64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4))) u32x4_u;  // a 16-byte vector at 4-byte alignment
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+#define MI_DEV __device__ __forceinline__
+
+// Geometry of one launch.  Coordinates are GLOBAL image coordinates: a strip launch passes a
+// buffer that holds only some rows of the image (in_lo/in_hi/in_origin describe which).
+struct Geo {
+    int W, H;             // image size
+    int batch;            // frames
+    int y_begin, y_end;   // output rows [y_begin, y_end)
+    int rows_per_band;    // rows one wave marches over
+    int bands, strips;    // per frame
+    int total_waves;      // batch * bands * strips
+    i64 N;                // W*H
+    i64 in_lo, in_hi;     // flat pixel indices [in_lo, in_hi) present in `in`
+    i64 in_origin;        // flat index of in[0]
+    i64 out_origin;       // flat index of out[0]
+    i64 in_frame_stride;  // pixels between frames
+    i64 out_frame_stride;
+};
+
+// lane i <- lane i-1 (lane 0 <- 0)
+MI_DEV u32 from_left(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }
+// lane i <- lane i+1 (lane 63 <- 0)
+MI_DEV u32 from_right(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
+
+MI_DEV u32 pk_min(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
+                                                              __builtin_bit_cast(u16x2, b)));
+}
+MI_DEV u32 pk_max(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                              __builtin_bit_cast(u16x2, b)));
+}
+MI_DEV u32 pk_add(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+MI_DEV u32 pk_sub(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+
+// Four pixels at flat index f..f+3 of the global image; pixels outside the image (or outside
+// the rows present in `in`) read 0.  ALIGNED: every f passed is a multiple of 4 and `in` is
+// 16-byte aligned, so the fast path is one aligned dwordx4 load.
+template <bool ALIGNED>
+MI_DEV u32x4 load_px4(const u32* __restrict__ in, const Geo& g, i64 f)
+{
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (f >= g.in_lo && f + 4 <= g.in_hi) {
+        const u32* p = in + (f - g.in_origin);
+        if (ALIGNED) v = *reinterpret_cast<const u32x4*>(p);
+        else v = *reinterpret_cast<const u32x4_u*>(p);
+    } else if (f + 4 > g.in_lo && f < g.in_hi) {
+        const u32* p = in + (f - g.in_origin);
+        if (f + 0 >= g.in_lo && f + 0 < g.in_hi) v.x = p[0];
+        if (f + 1 >= g.in_lo && f + 1 < g.in_hi) v.y = p[1];
+        if (f + 2 >= g.in_lo && f + 2 < g.in_hi) v.z = p[2];
+        if (f + 3 >= g.in_lo && f + 3 < g.in_hi) v.w = p[3];
+    }
+    return v;
+}
+
+// Store four output pixels of row y at columns cx..cx+3 (columns >= W are dropped).
+template <bool ALIGNED>
+MI_DEV void store_px4(u32* __restrict__ out, const Geo& g, int y, int cx, u32x4 v)
+{
+    u32* p = out + ((i64)y * g.W + cx - g.out_origin);
+    if (ALIGNED) {
+        *reinterpret_cast<u32x4*>(p) = v;   // W%4==0 and cx%4==0: cx<W implies cx+4<=W
+    } else if (cx + 4 <= g.W) {
+        *reinterpret_cast<u32x4_u*>(p) = v;
+    } else {
+        if (cx + 0 < g.W) p[0] = v.x;
+        if (cx + 1 < g.W) p[1] = v.y;
+        if (cx + 2 < g.W) p[2] = v.z;
+    }
+}
+
+// Work assignment of a wave.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b+8
+// share an L2), so logical block ids are remapped to give each XCD a contiguous run of
+// strips/bands: neighbouring waves, which re-read each other's halo rows and margin columns,
+// then hit in the same L2.  The remap is a bijection for every grid size.
+struct WaveJob {
+    int frame, band, strip, lane;
+    bool valid;
+};
+
+MI_DEV WaveJob wave_job(const Geo& g)
+{
+    const int waves_per_block = blockDim.x >> 6;
+    const u32 nblk = gridDim.x, b = blockIdx.x;
+    const u32 q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const u32 logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int wid = (int)logical * waves_per_block + (int)(threadIdx.x >> 6);
+    wid = __builtin_amdgcn_readfirstlane(wid);
+    WaveJob j;
+    j.valid = wid < g.total_waves;
+    j.strip = wid % g.strips;
+    const int t = wid / g.strips;
+    j.band = t % g.bands;
+    j.frame = t / g.bands;
+    j.lane = threadIdx.x & 63;
+    return j;
+}
+
+// x-mask helper: 0xFFFFFFFF where column x lies in the reference's write set [1, W-2].
+MI_DEV u32 xmask(int x, int W) { return (x >= 1 && x <= W - 2) ? 0xFFFFFFFFu : 0u; }

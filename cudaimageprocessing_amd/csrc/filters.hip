@@ -1,0 +1,683 @@
+// filters.hip -- gfx950 kernels for the u8x4 -> u8x4 filters of the reference's imageTools API
+// (grayscale, Sobel, Gaussian, mean, median) and their launcher.
+//
+// Semantics follow kernels/imageTools.cu of the reference (citations at each kernel); the
+// execution scheme ("wave march", see common.h) is this library's own.
+// Build with -ffp-contract=off: every fused multiply-add is spelled out.
+#include "common.h"
+#include "internal.h"
+#include "median_network.h"
+
+namespace mi {
+
+// ============================================================================ grayscale
+// imageGrayScale, imageTools.cu:217-231: gray = (uchar)(0.299f*R + 0.587f*G + 0.114f*B) on
+// every pixel; out = (g,g,g,A_in).  The contraction is pinned:
+// fma(.114,B, fma(.299,R, .587*G)).
+MI_DEV u32 gray_px(u32 p)
+{
+    const float r = (float)(p & 0xffu), g = (float)((p >> 8) & 0xffu), b = (float)((p >> 16) & 0xffu);
+    const float t = 0.587f * g;
+    const float u = __builtin_fmaf(0.299f, r, t);
+    const float v = __builtin_fmaf(0.114f, b, u);
+    return (u32)v * 0x010101u + (p & 0xFF000000u);
+}
+
+// Flat over all pixels: one 16-byte load and one 16-byte store per lane per step, UNROLL
+// independent steps in flight per lane.
+template <bool ALIGNED, int UNROLL>
+__global__ __launch_bounds__(256) void gray_kernel(const u32* __restrict__ in,
+                                                   u32* __restrict__ out, i64 n_px)
+{
+    const i64 groups = (n_px + 3) >> 2;  // groups of 4 pixels
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 gidx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; gidx + (UNROLL - 1) * stride < groups - 1; gidx += UNROLL * stride) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const u32* p = in + 4 * (gidx + u * stride);
+            v[u] = ALIGNED ? *reinterpret_cast<const u32x4*>(p)
+                           : (u32x4)(*reinterpret_cast<const u32x4_u*>(p));
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            u32x4 o = {gray_px(v[u].x), gray_px(v[u].y), gray_px(v[u].z), gray_px(v[u].w)};
+            u32* q = out + 4 * (gidx + u * stride);
+            if (ALIGNED) *reinterpret_cast<u32x4*>(q) = o;
+            else *reinterpret_cast<u32x4_u*>(q) = o;
+        }
+    }
+    for (; gidx < groups; gidx += stride) {  // remainder, including the ragged last group
+        const i64 base = 4 * gidx;
+        for (int k = 0; k < 4 && base + k < n_px; k++) out[base + k] = gray_px(in[base + k]);
+    }
+}
+
+// ============================================================================ Sobel
+// imageSobelEdge, imageTools.cu:255-285.  Red channel only (:274-275).  Separated as
+// V(x) = t+2m+b, D(x) = b-t (vertical), Gx = V(x+1)-V(x-1), Gy = D(x-1)+2D(x)+D(x+1); all
+// exact in 16-bit integers.  magnitude = trunc(clamp(sqrt(Gx^2+Gy^2),0,255)) (:278-282) is
+// evaluated as min(255, (uint)sqrt(s + 0.5f)): s is an integer, so the +0.5 keeps the argument
+// >= 1/(4*255) away from every perfect square and v_sqrt_f32's 1-ulp error cannot cross it
+// (swept exhaustively by tests/test_gpu_parity.py through mi_debug_sobel_mag_table_dev).
+MI_DEV u32 sobel_mag(int s)
+{
+    const float f = __builtin_amdgcn_sqrtf((float)s + 0.5f);
+    u32 m = (u32)f;
+    return m > 255u ? 255u : m;
+}
+
+MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
+{   // (r0 | r1<<16), (r2 | r3<<16): the red bytes of 4 pixels as packed u16
+    r01 = __builtin_amdgcn_perm(p.y, p.x, 0x0c040c00u);
+    r23 = __builtin_amdgcn_perm(p.w, p.z, 0x0c040c00u);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
+                                                    u32* __restrict__ out, const Geo g)
+{
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
+    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
+    const int y0 = g.y_begin + j.band * g.rows_per_band;
+    const int y1 = min(y0 + g.rows_per_band, g.y_end);
+    in += (i64)j.frame * g.in_frame_stride;
+    out += (i64)j.frame * g.out_frame_stride;
+    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const u32 xm0 = xmask(cx, g.W), xm1 = xmask(cx + 1, g.W), xm2 = xmask(cx + 2, g.W),
+              xm3 = xmask(cx + 3, g.W);
+
+    u32 t01, t23, m01, m23, b01, b23;
+    red_pairs(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), t01, t23);
+    red_pairs(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), m01, m23);
+    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
+    for (int y = y0; y < y1; y++) {
+        red_pairs(nxt, b01, b23);
+        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);  // prefetch the next row
+        const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
+        const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
+        const u32 D01 = pk_sub(b01, t01), D23 = pk_sub(b23, t23);
+        const u32 VL = from_left(V23), VR = from_right(V01);
+        const u32 DL = from_left(D23), DR = from_right(D01);
+        const u32 Va = __builtin_amdgcn_alignbit(V01, VL, 16);  // (V-1, V0)
+        const u32 Vb = __builtin_amdgcn_alignbit(V23, V01, 16); // (V1, V2)
+        const u32 Vc = __builtin_amdgcn_alignbit(VR, V23, 16);  // (V3, V4)
+        const u32 Da = __builtin_amdgcn_alignbit(D01, DL, 16);
+        const u32 Db = __builtin_amdgcn_alignbit(D23, D01, 16);
+        const u32 Dc = __builtin_amdgcn_alignbit(DR, D23, 16);
+        const u32 Gx01 = pk_sub(Vb, Va), Gx23 = pk_sub(Vc, Vb);
+        const u32 Gy01 = pk_add(pk_add(Da, Db), pk_add(D01, D01));
+        const u32 Gy23 = pk_add(pk_add(Db, Dc), pk_add(D23, D23));
+        // (Gx_j, Gy_j) as one s16x2, s_j = Gx_j^2 + Gy_j^2 with one dot2
+        const u32 P0 = __builtin_amdgcn_perm(Gy01, Gx01, 0x05040100u);
+        const u32 P1 = __builtin_amdgcn_perm(Gy01, Gx01, 0x07060302u);
+        const u32 P2 = __builtin_amdgcn_perm(Gy23, Gx23, 0x05040100u);
+        const u32 P3 = __builtin_amdgcn_perm(Gy23, Gx23, 0x07060302u);
+        const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+        u32x4 o;
+        o.x = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P0), __builtin_bit_cast(s16x2, P0), 0, false)) * 0x010101u | 0xFF000000u) & xm0 & rowm;
+        o.y = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P1), __builtin_bit_cast(s16x2, P1), 0, false)) * 0x010101u | 0xFF000000u) & xm1 & rowm;
+        o.z = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P2), __builtin_bit_cast(s16x2, P2), 0, false)) * 0x010101u | 0xFF000000u) & xm2 & rowm;
+        o.w = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P3), __builtin_bit_cast(s16x2, P3), 0, false)) * 0x010101u | 0xFF000000u) & xm3 & rowm;
+        if (productive) store_px4<ALIGNED>(out, g, y, cx, o);
+        t01 = m01; t23 = m23; m01 = b01; m23 = b23;
+    }
+}
+
+__global__ void sobel_table_kernel(unsigned char* out, u32 count)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (unsigned char)sobel_mag((int)i);
+}
+
+// ============================================================================ mean 3x3
+// imageMeanBlur, imageTools.cu:313-340, at the wrapper's k=3 (:806): int sums of the 9 taps
+// per channel, integer division by 9, alpha 255.  Channels travel as packed u16 pairs
+// lo=(R,B), hi=(G,A); s/9 == (s*7282)>>16 exactly for s < 32768 (s <= 2295 here).
+MI_DEV void unpack_px(u32 p, u32& lo, u32& hi)
+{
+    lo = p & 0x00FF00FFu;
+    hi = (p >> 8) & 0x00FF00FFu;
+}
+
+MI_DEV u32 div9_pack(u32 lo, u32 hi)
+{
+    const u32 qr = ((lo & 0xFFFFu) * 7282u) >> 16;
+    const u32 qb = ((lo >> 16) * 7282u) & 0x00FF0000u;
+    const u32 qg = (((hi & 0xFFFFu) * 7282u) >> 8) & 0x0000FF00u;
+    return qr | qg | qb | 0xFF000000u;
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
+                                                    u32* __restrict__ out, const Geo g)
+{
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
+    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
+    const int y0 = g.y_begin + j.band * g.rows_per_band;
+    const int y1 = min(y0 + g.rows_per_band, g.y_end);
+    in += (i64)j.frame * g.in_frame_stride;
+    out += (i64)j.frame * g.out_frame_stride;
+    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+
+    // horizontal 3-sums of one row, per pixel, as (lo, hi) packed pairs
+    auto hsum = [&](u32x4 p, u32 (&hl)[4], u32 (&hh)[4]) {
+        u32 lo[6], hi[6];
+        unpack_px(from_left(p.w), lo[0], hi[0]);
+        unpack_px(p.x, lo[1], hi[1]);
+        unpack_px(p.y, lo[2], hi[2]);
+        unpack_px(p.z, lo[3], hi[3]);
+        unpack_px(p.w, lo[4], hi[4]);
+        unpack_px(from_right(p.x), lo[5], hi[5]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            hl[k] = pk_add(pk_add(lo[k], lo[k + 1]), lo[k + 2]);
+            hh[k] = pk_add(pk_add(hi[k], hi[k + 1]), hi[k + 2]);
+        }
+    };
+
+    u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
+    hsum(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), tl, th);
+    hsum(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), ml, mh);
+    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
+    for (int y = y0; y < y1; y++) {
+        hsum(nxt, bl, bh);
+        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);
+        const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+        u32 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 sl = pk_add(pk_add(tl[k], ml[k]), bl[k]);
+            const u32 sh = pk_add(pk_add(th[k], mh[k]), bh[k]);
+            o[k] = div9_pack(sl, sh) & xm[k] & rowm;
+            tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k];
+        }
+        if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+// ============================================================================ median 3x3
+// Median blur (advertised in the reference's README.md:3, no reference code): per channel
+// the 5th smallest of the 9 flat taps, alpha 255, same write set as the other stencils.
+// Wave-register sorting network on packed u16 pairs (v_pk_min_u16 / v_pk_max_u16): each
+// 3-pixel column is sorted once per row and shared by the three outputs that use it
+// (the neighbours' sorted edge columns arrive by DPP); then
+// median9 = med3( max3(lows), med3(mids), min3(highs) ).
+MI_DEV void sort2(u32& a, u32& b)
+{
+    const u32 lo = pk_min(a, b), hi = pk_max(a, b);
+    a = lo; b = hi;
+}
+MI_DEV u32 med3(u32 a, u32 b, u32 c)
+{
+    return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in,
+                                                      u32* __restrict__ out, const Geo g)
+{
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
+    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
+    const int y0 = g.y_begin + j.band * g.rows_per_band;
+    const int y1 = min(y0 + g.rows_per_band, g.y_end);
+    in += (i64)j.frame * g.in_frame_stride;
+    out += (i64)j.frame * g.out_frame_stride;
+    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+
+    auto unpack4 = [&](u32x4 p, u32 (&l)[4], u32 (&h)[4]) {
+        unpack_px(p.x, l[0], h[0]); unpack_px(p.y, l[1], h[1]);
+        unpack_px(p.z, l[2], h[2]); unpack_px(p.w, l[3], h[3]);
+    };
+
+    u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
+    unpack4(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), tl, th);
+    unpack4(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), ml, mh);
+    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
+    for (int y = y0; y < y1; y++) {
+        unpack4(nxt, bl, bh);
+        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);
+        // sorted columns: index 0 = left neighbour's column 3, 1..4 = own, 5 = right's column 0
+        u32 cl[6][2], cm[6][2], ch[6][2];   // [column][0=lo pair (R,B), 1=hi pair (G,A)]
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 a = tl[k], b = ml[k], c = bl[k];
+            sort2(a, b); sort2(b, c); sort2(a, b);
+            cl[k + 1][0] = a; cm[k + 1][0] = b; ch[k + 1][0] = c;
+            a = th[k]; b = mh[k]; c = bh[k];
+            sort2(a, b); sort2(b, c); sort2(a, b);
+            cl[k + 1][1] = a; cm[k + 1][1] = b; ch[k + 1][1] = c;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            cl[0][s] = from_left(cl[4][s]); cm[0][s] = from_left(cm[4][s]); ch[0][s] = from_left(ch[4][s]);
+            cl[5][s] = from_right(cl[1][s]); cm[5][s] = from_right(cm[1][s]); ch[5][s] = from_right(ch[1][s]);
+        }
+        const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+        u32 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 r[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const u32 a = pk_max(pk_max(cl[k][s], cl[k + 1][s]), cl[k + 2][s]);
+                const u32 b = med3(cm[k][s], cm[k + 1][s], cm[k + 2][s]);
+                const u32 c = pk_min(pk_min(ch[k][s], ch[k + 1][s]), ch[k + 2][s]);
+                r[s] = med3(a, b, c);
+            }
+            o[k] = (r[0] | (r[1] << 8) | 0xFF000000u) & xm[k] & rowm;
+            tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k];
+        }
+        if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+
+// ============================================================================ Gaussian, separable
+// imageGaussianBlur, imageTools.cu:287-311, as a row pass followed by a column pass with the
+// normalised 1-D weights w (w x w^T equals generateGaussianKernal's 2-D kernel up to rounding).
+// The row pass runs on every input row as it is loaded; the K most recent row-pass results
+// stay in registers and feed the column pass.  fp32 throughout, truncating store (:306-308),
+// alpha 255, flat-index taps.  Differences against the reference's 2-D summation order are
+// rounding only: max |delta| = 1 LSB after truncation.
+struct GaussW { float w[16]; };
+
+template <int R, bool ALIGNED>
+__global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ in,
+                                                        u32* __restrict__ out, const Geo g,
+                                                        const GaussW gw)
+{
+    constexpr int K = 2 * R + 1;
+    constexpr int M = (R + 3) / 4;
+    constexpr int OUTW = 4 * (64 - 2 * M);
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
+    const int y0 = g.y_begin + j.band * g.rows_per_band;
+    const int y1 = min(y0 + g.rows_per_band, g.y_end);
+    in += (i64)j.frame * g.in_frame_stride;
+    out += (i64)j.frame * g.out_frame_stride;
+    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+
+    // Row pass: h[3*k+c] = sum_t w[t] * channel c of column (k - R + t), k = 0..3.
+    auto hrow = [&](u32x4 p, float (&h)[12]) {
+        u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
+        col[8] = p.x; col[9] = p.y; col[10] = p.z; col[11] = p.w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[4 + k] = from_left(col[8 + k]);
+            col[12 + k] = from_right(col[8 + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[k] = from_left(col[4 + k]);
+            col[16 + k] = from_right(col[12 + k]);
+        }
+        float f[4 + 2 * R][3];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * R; i++) {
+            const u32 v = col[8 - R + i];
+            f[i][0] = (float)(v & 0xffu);
+            f[i][1] = (float)((v >> 8) & 0xffu);
+            f[i][2] = (float)((v >> 16) & 0xffu);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float s = gw.w[0] * f[k][c];
+#pragma unroll
+                for (int t = 1; t < K; t++) s = __builtin_fmaf(gw.w[t], f[k + t][c], s);
+                h[3 * k + c] = s;
+            }
+    };
+
+    float win[K][12];
+    // rows y0-R .. y0+R-1 fill slots 0 .. K-2
+#pragma unroll
+    for (int i = 0; i < K - 1; i++)
+        hrow(load_px4<ALIGNED>(in, g, (i64)(y0 - R + i) * g.W + cx), win[i]);
+    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + R) * g.W + cx);
+
+    for (int base = y0; base < y1; base += K) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int y = base + s;
+            if (y < y1) {
+            // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
+            hrow(nxt, win[(K - 1 + s) % K]);
+            nxt = load_px4<ALIGNED>(in, g, (i64)(y + R + 1) * g.W + cx);
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float acc[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float a = gw.w[0] * win[s % K][3 * k + c];
+#pragma unroll
+                    for (int t = 1; t < K; t++) a = __builtin_fmaf(gw.w[t], win[(s + t) % K][3 * k + c], a);
+                    acc[c] = a;
+                }
+                o[k] = ((u32)acc[0] | ((u32)acc[1] << 8) | ((u32)acc[2] << 16) | 0xFF000000u) & xm[k] & rowm;
+            }
+            if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+            }
+        }
+    }
+}
+
+// ============================================================================ generic kernels
+// One thread per pixel, taps read one by one through the cache: the fallback for kernel sizes
+// without a specialised kernel, and the bit-exact "direct" Gaussian.
+struct Weights2D { float w[15 * 15]; };
+
+MI_DEV u32 tap_px(const u32* __restrict__ in, const Geo& g, i64 f)
+{
+    return (f >= g.in_lo && f < g.in_hi) ? in[f - g.in_origin] : 0u;
+}
+
+// imageGaussianBlur, imageTools.cu:287-311, in the reference's own order: ky outer, kx inner,
+// sum = fmaf(pixel, weight, sum) from 0, truncating store.  Bit-exact against the oracle.
+__global__ __launch_bounds__(256) void gauss_direct_kernel(const u32* __restrict__ in,
+                                                           u32* __restrict__ out, const Geo g,
+                                                           int k, const Weights2D wt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = g.y_begin + blockIdx.y;
+    const int frame = blockIdx.z;
+    if (x >= g.W) return;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    u32 o = 0;
+    if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2) {
+        const int r = k / 2;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int ky = -r; ky <= r; ky++)
+            for (int kx = -r; kx <= r; kx++) {
+                const u32 p = tap_px(in, g, (i64)(y + ky) * g.W + (x + kx));
+                const float kv = wt.w[(ky + r) * k + (kx + r)];
+                sx = __builtin_fmaf((float)(p & 0xffu), kv, sx);
+                sy = __builtin_fmaf((float)((p >> 8) & 0xffu), kv, sy);
+                sz = __builtin_fmaf((float)((p >> 16) & 0xffu), kv, sz);
+            }
+        o = (u32)sx | ((u32)sy << 8) | ((u32)sz << 16) | 0xFF000000u;
+    }
+    out[(i64)y * g.W + x - g.out_origin] = o;
+}
+
+// imageMeanBlur, imageTools.cu:313-340, for any odd k.
+__global__ __launch_bounds__(256) void mean_generic_kernel(const u32* __restrict__ in,
+                                                           u32* __restrict__ out, const Geo g,
+                                                           int k)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = g.y_begin + blockIdx.y;
+    const int frame = blockIdx.z;
+    if (x >= g.W) return;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    u32 o = 0;
+    if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2) {
+        const int r = k / 2;
+        int mx = 0, my = 0, mz = 0;
+        for (int ky = -r; ky <= r; ky++)
+            for (int kx = -r; kx <= r; kx++) {
+                const u32 p = tap_px(in, g, (i64)(y + ky) * g.W + (x + kx));
+                mx += (int)(p & 0xffu); my += (int)((p >> 8) & 0xffu); mz += (int)((p >> 16) & 0xffu);
+            }
+        const int d = k * k;
+        o = (u32)(mx / d) | ((u32)(my / d) << 8) | ((u32)(mz / d) << 16) | 0xFF000000u;
+    }
+    out[(i64)y * g.W + x - g.out_origin] = o;
+}
+
+// Median 5x5: 13th smallest of the 25 flat taps per channel, one pixel per lane, selection
+// network (median_network.h) on packed u16 pairs.
+__global__ __launch_bounds__(256) void median5_kernel(const u32* __restrict__ in,
+                                                      u32* __restrict__ out, const Geo g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = g.y_begin + blockIdx.y;
+    const int frame = blockIdx.z;
+    if (x >= g.W) return;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    u32 o = 0;
+    if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2) {
+        u32 lo[25], hi[25];
+#pragma unroll
+        for (int ky = -2; ky <= 2; ky++)
+#pragma unroll
+            for (int kx = -2; kx <= 2; kx++) {
+                const u32 p = tap_px(in, g, (i64)(y + ky) * g.W + (x + kx));
+                unpack_px(p, lo[(ky + 2) * 5 + kx + 2], hi[(ky + 2) * 5 + kx + 2]);
+            }
+        struct CE { MI_DEV void operator()(u32& a, u32& b) const { sort2(a, b); } };
+        const u32 mlo = median25_select(lo, CE{});
+        const u32 mhi = median25_select(hi, CE{});
+        o = mlo | (mhi << 8) | 0xFF000000u;
+    }
+    out[(i64)y * g.W + x - g.out_origin] = o;
+}
+
+// ============================================================================ utility kernels
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src,
+                                                     u32x4* __restrict__ dst, i64 n16)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void copy1_kernel(const unsigned char* __restrict__ src,
+                                                    unsigned char* __restrict__ dst, i64 n)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void synth_kernel(u32* __restrict__ out, uint64_t seed,
+                                                    uint64_t first, uint64_t count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint64_t z = seed * 0x9E3779B97F4A7C15ULL + (first + i) + 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z ^= z >> 31;
+        out[i] = (u32)z | 0xFF000000u;
+    }
+}
+
+// ============================================================================ launcher
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static int grid_cap() { return 256 * 8; }  // 256 CUs x 8 blocks of 256 threads
+
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return MI_OK;
+    if ((((uintptr_t)src | (uintptr_t)dst | bytes) & 15) == 0) {
+        const i64 n16 = (i64)(bytes >> 4);
+        const int grid = (int)std::min<i64>((n16 + 255) / 256, grid_cap());
+        copy16_kernel<<<grid, 256, 0, s>>>((const u32x4*)src, (u32x4*)dst, n16);
+    } else {
+        const int grid = (int)std::min<i64>(((i64)bytes + 255) / 256, grid_cap());
+        copy1_kernel<<<grid, 256, 0, s>>>((const unsigned char*)src, (unsigned char*)dst, (i64)bytes);
+    }
+    return hip_status(hipGetLastError(), "copy kernel launch");
+}
+
+int launch_synth(void* out, uint64_t seed, uint64_t first, uint64_t count, hipStream_t s)
+{
+    if (count == 0) return MI_OK;
+    const int grid = (int)std::min<uint64_t>((count + 255) / 256, (uint64_t)grid_cap() * 4);
+    synth_kernel<<<grid, 256, 0, s>>>((u32*)out, seed, first, count);
+    return hip_status(hipGetLastError(), "synth kernel launch");
+}
+
+int launch_sobel_table(void* out, uint32_t count, hipStream_t s)
+{
+    if (count == 0) return MI_OK;
+    sobel_table_kernel<<<(count + 255) / 256, 256, 0, s>>>((unsigned char*)out, count);
+    return hip_status(hipGetLastError(), "sobel table kernel launch");
+}
+
+int filter_halo_rows(int filter, int ksize)
+{
+    switch (filter) {
+    case MI_FILTER_GRAYSCALE: return 0;
+    case MI_FILTER_SOBEL: return 1;
+    case MI_FILTER_GAUSSIAN:
+    case MI_FILTER_GAUSSIAN_DIRECT:
+    case MI_FILTER_MEAN:
+    case MI_FILTER_MEDIAN: {
+        const int r = ksize / 2;
+        return r <= 1 ? 1 : r + 1;  // r>1: one more row for the flat-index wrap
+    }
+    default: return -1;
+    }
+}
+
+template <int R>
+static void launch_gauss_sep(bool aligned, int grid, hipStream_t s, const u32* in, u32* out,
+                             const Geo& g, const GaussW& gw)
+{
+    if (aligned) gauss_sep_kernel<R, true><<<grid, 256, 0, s>>>(in, out, g, gw);
+    else gauss_sep_kernel<R, false><<<grid, 256, 0, s>>>(in, out, g, gw);
+}
+
+int launch_filter(const FilterArgs& a)
+{
+    const int W = a.w, H = a.h_total;
+    const u32* in = (const u32*)a.in;
+    u32* out = (u32*)a.out;
+    const i64 in_frame = (i64)a.in_rows * W, out_frame = (i64)(a.y_end - a.y_begin) * W;
+    const bool aligned = (W % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+
+    if (a.filter == MI_FILTER_GRAYSCALE) {
+        // Point op: a flat pass over the output rows.  When the input holds exactly the output
+        // rows, all frames are one contiguous run of pixels and take a single launch.
+        const bool contiguous = (a.in_row0 == a.y_begin && in_frame == out_frame);
+        const i64 skip = (i64)(a.y_begin - a.in_row0) * W;
+        const int launches = contiguous ? 1 : a.batch;
+        for (int f = 0; f < launches; f++) {
+            const i64 n = contiguous ? out_frame * a.batch : out_frame;
+            const u32* src = in + (i64)f * in_frame + skip;
+            u32* dst = out + (i64)f * out_frame;
+            const bool al = ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+            const i64 groups = (n + 3) / 4;
+            const int grid = (int)std::max<i64>(1, std::min<i64>((groups + 256 * 4 - 1) / (256 * 4), grid_cap()));
+            if (al) gray_kernel<true, 4><<<grid, 256, 0, a.stream>>>(src, dst, n);
+            else gray_kernel<false, 4><<<grid, 256, 0, a.stream>>>(src, dst, n);
+        }
+        return hip_status(hipGetLastError(), "grayscale kernel launch");
+    }
+
+    Geo g;
+    g.W = W; g.H = H; g.batch = a.batch;
+    g.y_begin = a.y_begin; g.y_end = a.y_end;
+    g.N = (i64)W * H;
+    g.in_origin = (i64)a.in_row0 * W;
+    g.in_lo = std::max<i64>(0, g.in_origin);
+    g.in_hi = std::min<i64>(g.N, (i64)(a.in_row0 + a.in_rows) * W);
+    g.out_origin = (i64)a.y_begin * W;
+    g.in_frame_stride = in_frame;
+    g.out_frame_stride = out_frame;
+    const int rows = a.y_end - a.y_begin;
+
+    // generic one-thread-per-pixel kernels
+    const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT;
+    const bool mean_generic = a.filter == MI_FILTER_MEAN && a.ksize != 3;
+    const bool median5 = a.filter == MI_FILTER_MEDIAN && a.ksize == 5;
+    if (direct || mean_generic || median5) {
+        g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0;
+        for (int f0 = 0; f0 < a.batch; f0 += 65535) {
+            const int nb = std::min(65535, a.batch - f0);
+            for (int r0 = 0; r0 < rows; r0 += 65535) {
+                const int nr = std::min(65535, rows - r0);
+                Geo gg = g;
+                gg.y_begin = a.y_begin + r0;
+                const dim3 grid((W + 255) / 256, nr, nb);
+                const u32* pin = in + (i64)f0 * in_frame;
+                u32* pout = out + (i64)f0 * out_frame;
+                if (direct) {
+                    Weights2D wt;
+                    gaussian_kernel_2d(a.ksize, a.sigma, wt.w);
+                    gauss_direct_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize, wt);
+                } else if (mean_generic) {
+                    mean_generic_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize);
+                } else {
+                    median5_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg);
+                }
+            }
+        }
+        return hip_status(hipGetLastError(), "generic filter kernel launch");
+    }
+
+    // wave-march kernels
+    int margin = 1;
+    if (a.filter == MI_FILTER_GAUSSIAN) margin = (a.ksize / 2 + 3) / 4;
+    const int outw = 4 * (64 - 2 * margin);
+    g.strips = (W + outw - 1) / outw;
+    int rpb = env_int("MI_ROWS_PER_BAND", 0);
+    if (rpb <= 0) {
+        // enough waves to fill 256 CUs x 4 SIMDs several times over, bands as tall as that allows
+        rpb = 32;
+        while (rpb > 8 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < 8192) rpb >>= 1;
+    }
+    g.rows_per_band = rpb;
+    g.bands = (rows + rpb - 1) / rpb;
+    const i64 total = (i64)a.batch * g.bands * g.strips;
+    if (total > 0x7fffffff / 64) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
+    g.total_waves = (int)total;
+    const int grid = (int)((total + 3) / 4);
+
+    switch (a.filter) {
+    case MI_FILTER_SOBEL:
+        if (aligned) sobel_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
+        else sobel_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+        break;
+    case MI_FILTER_MEAN:
+        if (aligned) mean3_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
+        else mean3_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+        break;
+    case MI_FILTER_MEDIAN:
+        if (aligned) median3_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
+        else median3_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+        break;
+    case MI_FILTER_GAUSSIAN: {
+        GaussW gw;
+        gaussian_kernel_1d(a.ksize, a.sigma, gw.w);
+        switch (a.ksize / 2) {
+        case 1: launch_gauss_sep<1>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 2: launch_gauss_sep<2>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 3: launch_gauss_sep<3>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 4: launch_gauss_sep<4>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 5: launch_gauss_sep<5>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 6: launch_gauss_sep<6>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 7: launch_gauss_sep<7>(aligned, grid, a.stream, in, out, g, gw); break;
+        default: return fail(MI_ERR_BAD_KERNEL_SIZE, "separable Gaussian supports kernel sizes 3..15");
+        }
+        break;
+    }
+    default:
+        return fail(MI_ERR_INVALID_ARG, "unknown filter %d", a.filter);
+    }
+    return hip_status(hipGetLastError(), "filter kernel launch");
+}
+
+}  // namespace mi

@@ -1,0 +1,54 @@
+// internal.h -- host-side declarations shared by the translation units of libmi_imagetools.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mi_imagetools.h"
+
+namespace mi {
+
+// Records `msg` as the calling thread's last error and returns `code`.
+int fail(int code, const char* fmt, ...);
+// Maps a hipError_t to the ABI's return value (0 or the positive error code), recording it.
+int hip_status(hipError_t e, const char* what);
+
+// One filter launch over a (strip of a) batch of frames; see Geo in common.h for the meaning
+// of the row arguments.  All pointers are device pointers.
+struct FilterArgs {
+    int filter;            // MI_FILTER_*
+    const void* in;
+    void* out;
+    int w, h_total;
+    int batch;
+    int in_row0, in_rows;  // rows present in `in` (per frame)
+    int y_begin, y_end;    // output rows, out row 0 == y_begin
+    int ksize;
+    float sigma;
+    hipStream_t stream;
+};
+int launch_filter(const FilterArgs& a);
+int filter_halo_rows(int filter, int ksize);
+
+// generateGaussianKernal restated for the library (host code; imageTools.cu:362-385).
+void gaussian_kernel_2d(int k, float sigma, float* out);
+// Normalised 1-D weights whose outer product is the 2-D kernel (up to rounding).
+void gaussian_kernel_1d(int k, float sigma, float* out);
+
+int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
+int launch_synth(void* out, uint64_t seed, uint64_t first, uint64_t count, hipStream_t s);
+int launch_sobel_table(void* out, uint32_t count, hipStream_t s);
+
+// FFT path
+int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);
+int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s);
+int launch_fftshift(void* d, int w, int h, hipStream_t s);
+int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s);
+int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);
+int launch_complex_to_u8(const void* r, const void* g, const void* b, void* out, int w, int h,
+                         hipStream_t s);
+int launch_minmax(const void* img, size_t n, void* minmax, hipStream_t s);
+int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* minmax,
+                           hipStream_t s);
+
+}  // namespace mi

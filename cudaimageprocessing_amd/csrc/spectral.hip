@@ -1,0 +1,210 @@
+// spectral.hip -- the pointwise kernels of the reference's FFT demo path
+// (imageFFTImageGenerate, kernels/imageTools.cu:633-791) and the normalise helpers (:416-471).
+// The 2-D transform itself lives in fft.hip.
+#include "common.h"
+#include "internal.h"
+
+namespace mi {
+
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+static int flat_grid(i64 n, int per_thread = 1)
+{
+    const i64 blocks = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    return (int)std::max<i64>(1, std::min<i64>(blocks, 256 * 16));
+}
+
+// uchar4ToCufftComplex, imageTools.cu:506-515: plane_c[idx] = (float(c), 0).
+__global__ __launch_bounds__(256) void u8_to_complex_kernel(const u32* __restrict__ in,
+                                                            f32x2v* __restrict__ r,
+                                                            f32x2v* __restrict__ g,
+                                                            f32x2v* __restrict__ b, i64 n)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 p = in[i];
+        r[i] = f32x2v{(float)(p & 0xffu), 0.0f};
+        g[i] = f32x2v{(float)((p >> 8) & 0xffu), 0.0f};
+        b[i] = f32x2v{(float)((p >> 16) & 0xffu), 0.0f};
+    }
+}
+
+// ComplexRGBToUchar, imageTools.cu:517-527; the undefined float->uchar cast of out-of-range
+// values is defined as saturate (NaN -> 0).
+MI_DEV u32 sat_u8(float v)
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (u32)v;
+}
+
+__global__ __launch_bounds__(256) void complex_to_u8_kernel(const f32x2v* __restrict__ r,
+                                                            const f32x2v* __restrict__ g,
+                                                            const f32x2v* __restrict__ b,
+                                                            u32* __restrict__ out, i64 n)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = sat_u8(r[i].x) | (sat_u8(g[i].x) << 8) | (sat_u8(b[i].x) << 16) | 0xFF000000u;
+}
+
+// fftShift, imageTools.cu:564-583: swap quadrants 1<->3 and 2<->4 for x<W/2, y<H/2.
+__global__ __launch_bounds__(256) void fftshift_kernel(f32x2v* __restrict__ d, int w, int h)
+{
+    const int hw = w / 2, hh = h / 2;
+    const i64 n = (i64)hw * hh, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / hw), x = (int)(i % hw);
+        const i64 i1 = (i64)y * w + x, i2 = (i64)(y + hh) * w + (x + hw);
+        const i64 i3 = (i64)y * w + (x + hw), i4 = (i64)(y + hh) * w + x;
+        const f32x2v a = d[i1], b = d[i2], c = d[i3], e = d[i4];
+        d[i1] = b; d[i2] = a; d[i3] = e; d[i4] = c;
+    }
+}
+
+// highpassFilter, imageTools.cu:530-549.
+__global__ __launch_bounds__(256) void highpass_kernel(f32x2v* __restrict__ d, int w, int h,
+                                                       float cutoff)
+{
+    const i64 n = (i64)w * h, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int y = (int)(i / w), x = (int)(i % w);
+        const float cx = (float)x - (float)w / 2.0f;
+        const float cy = (float)y - (float)h / 2.0f;
+        const float distance = sqrtf(cx * cx + cy * cy);
+        const float gain = 1.0f - expf(-(distance * distance) / (2.0f * cutoff * cutoff));
+        f32x2v v = d[i];
+        v.x *= gain; v.y *= gain;
+        d[i] = v;
+    }
+}
+
+// NormalizeAndZeroImaginary, imageTools.cu:551-562: re /= (float)(W*H), im = 0.
+__global__ __launch_bounds__(256) void normalize_zero_imag_kernel(f32x2v* __restrict__ d, i64 n,
+                                                                  float div)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        d[i] = f32x2v{d[i].x / div, 0.0f};
+}
+
+// findMinMax, imageTools.cu:416-454: global min/max of a float image.  Wave reduce by DPP-free
+// shuffles, one block result in LDS, then one ordered-int atomic per block: for IEEE floats the
+// signed-int order of the bit patterns matches the float order for non-negative values and is
+// reversed for negative ones, so min/max are taken on a monotone integer key.  NaNs are skipped
+// (the reference's CAS loop would spin forever on NaN).
+MI_DEV int f2key(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : (int)(0x80000000u - (u32)i);
+}
+MI_DEV float key2f(int k)
+{
+    return __int_as_float(k >= 0 ? k : (int)(0x80000000u - (u32)k));
+}
+
+__global__ void minmax_init_kernel(int* keys)
+{
+    keys[0] = 0x7fffffff;
+    keys[1] = (int)0x80000000;
+}
+
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ img, i64 n,
+                                                     int* __restrict__ keys)
+{
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = img[i];
+        if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    __shared__ float smn[4], smx[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smn[wave] = mn; smx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { mn = fminf(mn, smn[k]); mx = fmaxf(mx, smx[k]); }
+        if (mn <= mx) {
+            atomicMin(&keys[0], f2key(mn));
+            atomicMax(&keys[1], f2key(mx));
+        }
+    }
+}
+
+__global__ void minmax_final_kernel(const int* keys, float* out)
+{
+    out[0] = key2f(keys[0]);
+    out[1] = key2f(keys[1]);
+}
+
+// floatToUchar4, imageTools.cu:458-471, after the scaling the reference never wrote:
+// v' = (v-min)/(max-min)*255 (0 when max==min), saturating truncation, out=(v',v',v',255).
+__global__ __launch_bounds__(256) void normalize_to_u8_kernel(const float* __restrict__ img,
+                                                              u32* __restrict__ out, i64 n,
+                                                              const float* __restrict__ minmax)
+{
+    const float mn = minmax[0], range = minmax[1] - minmax[0];
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = range > 0.0f ? (img[i] - mn) / range * 255.0f : 0.0f;
+        out[i] = sat_u8(v) * 0x010101u | 0xFF000000u;
+    }
+}
+
+int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s)
+{
+    const i64 n = (i64)w * h;
+    u8_to_complex_kernel<<<flat_grid(n), 256, 0, s>>>((const u32*)in, (f32x2v*)r, (f32x2v*)g, (f32x2v*)b, n);
+    return hip_status(hipGetLastError(), "u8_to_complex launch");
+}
+
+int launch_complex_to_u8(const void* r, const void* g, const void* b, void* out, int w, int h, hipStream_t s)
+{
+    const i64 n = (i64)w * h;
+    complex_to_u8_kernel<<<flat_grid(n), 256, 0, s>>>((const f32x2v*)r, (const f32x2v*)g, (const f32x2v*)b, (u32*)out, n);
+    return hip_status(hipGetLastError(), "complex_to_u8 launch");
+}
+
+int launch_fftshift(void* d, int w, int h, hipStream_t s)
+{
+    const i64 n = (i64)(w / 2) * (h / 2);
+    if (n == 0) return MI_OK;
+    fftshift_kernel<<<flat_grid(n), 256, 0, s>>>((f32x2v*)d, w, h);
+    return hip_status(hipGetLastError(), "fftshift launch");
+}
+
+int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s)
+{
+    highpass_kernel<<<flat_grid((i64)w * h), 256, 0, s>>>((f32x2v*)d, w, h, cutoff);
+    return hip_status(hipGetLastError(), "highpass launch");
+}
+
+int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s)
+{
+    normalize_zero_imag_kernel<<<flat_grid((i64)w * h), 256, 0, s>>>((f32x2v*)d, (i64)w * h, (float)(w * h));
+    return hip_status(hipGetLastError(), "normalize_zero_imag launch");
+}
+
+// The {min,max} pair is reduced in place in the caller's 2-float result buffer, reinterpreted
+// as two ordered-int keys and converted back by the last kernel: no allocation.
+int launch_minmax(const void* img, size_t n, void* minmax, hipStream_t s)
+{
+    minmax_init_kernel<<<1, 1, 0, s>>>((int*)minmax);
+    minmax_kernel<<<flat_grid((i64)n, 8), 256, 0, s>>>((const float*)img, (i64)n, (int*)minmax);
+    minmax_final_kernel<<<1, 1, 0, s>>>((const int*)minmax, (float*)minmax);
+    return hip_status(hipGetLastError(), "minmax launch");
+}
+
+int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* minmax, hipStream_t s)
+{
+    normalize_to_u8_kernel<<<flat_grid((i64)n), 256, 0, s>>>((const float*)img, (u32*)out, (i64)n, (const float*)minmax);
+    return hip_status(hipGetLastError(), "normalize_to_u8 launch");
+}
+
+}  // namespace mi

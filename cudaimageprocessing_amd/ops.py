@@ -1,0 +1,280 @@
+"""Host-side mirror of the reference's imageTools interface over the C ABI.
+
+Two families, both thin (all arithmetic happens in libmi_imagetools.so):
+
+* device tier -- functions on CUDA(HIP) torch tensors of dtype uint8 and shape (..., H, W, 4);
+  asynchronous on torch's current stream.  torch is used only for device memory and streams.
+* host tier -- the reference's wrapper names (kernels/imageTools.h:10-18) on numpy arrays,
+  blocking, same argument order: imageGrayScaleWrapper(returnImage, imageLoaded, width, height).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+# ---------------------------------------------------------------------------- device tier
+def _torch():
+    import torch
+    return torch
+
+
+def _stream():
+    return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+
+def _frames(t):
+    torch = _torch()
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError("device-tier ops take CUDA/HIP tensors; there is no CPU fallback")
+    if t.dtype != torch.uint8 or t.dim() < 3 or t.shape[-1] != 4 or not t.is_contiguous():
+        raise ValueError("expected a contiguous uint8 tensor of shape (..., H, W, 4)")
+    h, w = int(t.shape[-3]), int(t.shape[-2])
+    batch = 1
+    for d in t.shape[:-3]:
+        batch *= int(d)
+    return w, h, batch
+
+
+def _out_like(t, out):
+    if out is None:
+        return _torch().empty_like(t)
+    if out.shape != t.shape or out.dtype != t.dtype or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("out must match the input's shape, dtype and device")
+    return out
+
+
+def grayscale(img, out=None):
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    check(lib().mi_grayscale_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b, _stream()))
+    return out
+
+
+def sobel(img, out=None):
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    check(lib().mi_sobel_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b, _stream()))
+    return out
+
+
+def gaussian_blur(img, kernel_size, sigma, out=None, direct=False):
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    mode = _lib.GAUSS_DIRECT if direct else _lib.GAUSS_SEPARABLE
+    check(lib().mi_gaussian_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b, int(kernel_size),
+                                     float(sigma), mode, _stream()))
+    return out
+
+
+def mean_blur(img, kernel_size=3, out=None):
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    check(lib().mi_meanblur_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b, int(kernel_size), _stream()))
+    return out
+
+
+def median_blur(img, kernel_size=3, out=None):
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    check(lib().mi_medianblur_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b, int(kernel_size), _stream()))
+    return out
+
+
+def filter_chain(img, bufs=None, gauss_k=5, gauss_sigma=1.0, median_k=3):
+    """BASELINE.json config 2: gray -> Gaussian -> median -> Sobel.  Returns the four stage
+    outputs; `bufs` (4 tensors like img) lets a benchmark reuse its buffers."""
+    torch = _torch()
+    if bufs is None:
+        bufs = [torch.empty_like(img) for _ in range(4)]
+    grayscale(img, bufs[0])
+    gaussian_blur(bufs[0], gauss_k, gauss_sigma, bufs[1])
+    median_blur(bufs[1], median_k, bufs[2])
+    sobel(bufs[2], bufs[3])
+    return bufs
+
+
+def filter_strip(filter_id, strip_in, out, w, h_total, in_row0, y_begin, y_end, ksize=3, sigma=0.0):
+    """One row strip of a larger image (mi_filter_strip_u8x4_dev): strip_in holds global rows
+    [in_row0, in_row0 + strip_in.shape[0]); out receives rows [y_begin, y_end)."""
+    in_rows = int(strip_in.shape[0])
+    check(lib().mi_filter_strip_u8x4_dev(int(filter_id), strip_in.data_ptr(), out.data_ptr(), int(w),
+                                         int(h_total), int(in_row0), in_rows, int(y_begin), int(y_end),
+                                         int(ksize), float(sigma), _stream()))
+    return out
+
+
+def halo_rows(filter_id, ksize=3):
+    n = lib().mi_filter_halo_rows(int(filter_id), int(ksize))
+    if n < 0:
+        raise ValueError(f"unknown filter {filter_id}")
+    return n
+
+
+def synth(seed, w, h, batch=None, first_idx=0, device="cuda"):
+    """Synthetic frames generated on the device (same stream of pixels as oracle synth)."""
+    torch = _torch()
+    shape = (h, w, 4) if batch is None else (batch, h, w, 4)
+    out = torch.empty(shape, dtype=torch.uint8, device=device)
+    count = w * h * (1 if batch is None else batch)
+    check(lib().mi_synth_u8x4_dev(out.data_ptr(), int(seed), int(first_idx), count, _stream()))
+    return out
+
+
+def sobel_mag_table(count, device="cuda"):
+    torch = _torch()
+    out = torch.empty(count, dtype=torch.uint8, device=device)
+    check(lib().mi_debug_sobel_mag_table_dev(out.data_ptr(), count, _stream()))
+    return out
+
+
+def image_load(byte_tensor, out=None):
+    torch = _torch()
+    n_px = byte_tensor.numel() // 4
+    if out is None:
+        out = torch.empty(n_px * 4, dtype=torch.uint8, device=byte_tensor.device)
+    check(lib().mi_image_load_dev(byte_tensor.data_ptr(), out.data_ptr(), n_px, _stream()))
+    return out
+
+
+def image_write(pixels, out=None):
+    torch = _torch()
+    w, h, b = _frames(pixels)
+    assert b == 1
+    if out is None:
+        out = torch.empty(w * h * 4, dtype=torch.uint8, device=pixels.device)
+    check(lib().mi_image_write_dev(out.data_ptr(), pixels.data_ptr(), w, h, _stream()))
+    return out
+
+
+# FFT path --------------------------------------------------------------------------------
+def _plane(t):
+    torch = _torch()
+    if not (t.is_cuda and t.dtype == torch.complex64 and t.is_contiguous() and t.dim() >= 2):
+        raise ValueError("expected a contiguous complex64 CUDA tensor of shape (..., rows, cols)")
+    rows, cols = int(t.shape[-2]), int(t.shape[-1])
+    batch = 1
+    for d in t.shape[:-2]:
+        batch *= int(d)
+    return rows, cols, batch
+
+
+def u8_to_complex(img):
+    torch = _torch()
+    w, h, b = _frames(img)
+    assert b == 1
+    planes = [torch.empty((h, w), dtype=torch.complex64, device=img.device) for _ in range(3)]
+    check(lib().mi_u8_to_complex_dev(img.data_ptr(), planes[0].data_ptr(), planes[1].data_ptr(),
+                                     planes[2].data_ptr(), w, h, _stream()))
+    return planes
+
+
+def fft2d(x, inverse=False, out=None):
+    """Unnormalised 2-D complex DFT of the last two dims (cufftExecC2C's convention)."""
+    rows, cols, batch = _plane(x)
+    if out is None:
+        out = _torch().empty_like(x)
+    check(lib().mi_fft2d_c2c_f32_dev(x.data_ptr(), out.data_ptr(), rows, cols, batch,
+                                     _lib.FFT_INVERSE if inverse else _lib.FFT_FORWARD, _stream()))
+    return out
+
+
+def fftshift_(x):
+    rows, cols, batch = _plane(x)
+    assert batch == 1
+    check(lib().mi_fftshift_dev(x.data_ptr(), cols, rows, _stream()))
+    return x
+
+
+def highpass_(x, cutoff=10.0):
+    rows, cols, batch = _plane(x)
+    assert batch == 1
+    check(lib().mi_highpass_dev(x.data_ptr(), cols, rows, float(cutoff), _stream()))
+    return x
+
+
+def normalize_zero_imag_(x):
+    rows, cols, batch = _plane(x)
+    assert batch == 1
+    check(lib().mi_normalize_zero_imag_dev(x.data_ptr(), cols, rows, _stream()))
+    return x
+
+
+def complex_to_u8(red, green, blue):
+    torch = _torch()
+    rows, cols, _ = _plane(red)
+    out = torch.empty((rows, cols, 4), dtype=torch.uint8, device=red.device)
+    check(lib().mi_complex_to_u8_dev(red.data_ptr(), green.data_ptr(), blue.data_ptr(), out.data_ptr(),
+                                     cols, rows, _stream()))
+    return out
+
+
+def minmax(img):
+    torch = _torch()
+    assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+    out = torch.empty(2, dtype=torch.float32, device=img.device)
+    check(lib().mi_minmax_f32_dev(img.data_ptr(), img.numel(), out.data_ptr(), _stream()))
+    return out
+
+
+def normalize_to_u8(img, mm=None):
+    torch = _torch()
+    if mm is None:
+        mm = minmax(img)
+    out = torch.empty(tuple(img.shape) + (4,), dtype=torch.uint8, device=img.device)
+    check(lib().mi_normalize_to_u8_dev(img.data_ptr(), out.data_ptr(), img.numel(), mm.data_ptr(), _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------- host tier
+def _host_img(a, w, h):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]):
+        raise TypeError("host-tier wrappers take C-contiguous numpy uint8 arrays")
+    if a.size != w * h * 4:
+        raise ValueError(f"array has {a.size} bytes, expected {w * h * 4}")
+    return a.ctypes.data
+
+
+def imageLoadWrapper(image, imageLoaded, imgSize):
+    check(lib().mi_image_load(image.ctypes.data, imageLoaded.ctypes.data, int(imgSize)))
+
+
+def imageWriteWrapper(filename, pixels, width, height):
+    check(lib().mi_image_write(str(filename).encode(), _host_img(pixels, width, height), width, height))
+
+
+def imageGrayScaleWrapper(returnImage, imageLoaded, width, height):
+    check(lib().mi_grayscale_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height), width, height))
+
+
+def imageSobelEdgeWrapper(returnImage, imageLoaded, width, height):
+    check(lib().mi_sobel_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height), width, height))
+
+
+def imageGaussianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize, sigma, direct=False):
+    check(lib().mi_gaussian_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
+                                 width, height, int(kernalSize), float(sigma),
+                                 _lib.GAUSS_DIRECT if direct else _lib.GAUSS_SEPARABLE))
+
+
+def imageMeanBlurWrapper(returnImage, imageLoaded, width, height, kernalSize=3):
+    check(lib().mi_meanblur_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
+                                 width, height, int(kernalSize)))
+
+
+def imageMedianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize=3):
+    check(lib().mi_medianblur_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
+                                   width, height, int(kernalSize)))
+
+
+def imageFFTImageGenerate(returnImage, imageLoaded, width, height, cutoff=10.0):
+    check(lib().mi_fft_highpass_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
+                                     width, height, float(cutoff)))
+
+
+def generateGaussianKernal(kernalSize, sigma):
+    out = np.empty((kernalSize, kernalSize), np.float32)
+    check(lib().mi_gaussian_kernel(int(kernalSize), float(sigma), out.ctypes.data))
+    return out

@@ -1,0 +1,172 @@
+/*
+ * mi_imagetools.h -- C ABI of the MI355X (gfx950) image-filter library.
+ *
+ * This is the drop-in boundary for ctaylo41/CudaImageProcessing's L2 wrapper API
+ * (reference kernels/imageTools.h:10-19): every entry point below names the reference
+ * function it replaces.  The C++ header include/imageTools.h keeps the reference's own
+ * signatures as thin shims over these functions.
+ *
+ * Pixel format everywhere: RGBA, 4 bytes per pixel, row-major, pitch = width*4, no padding
+ * (the reference's uchar4 image, kernels/imageTools.cu:107-119; main.cpp:14).
+ *
+ * Two tiers:
+ *   host tier    mi_*(...)       host pointers, blocking, reference wrapper semantics
+ *                                (allocate, H2D, kernel, D2H -- kernels/imageTools.cu:233-253);
+ *                                `out` may alias `in` (main.cpp:38-43 always passes (img,img)).
+ *   device tier  mi_*_dev(...)   device pointers, asynchronous on `stream` (a hipStream_t
+ *                                passed as void*, NULL = the default stream); `out` must not
+ *                                overlap `in`.  This is the tier the benchmarks time.
+ *
+ * Return value: 0 (MI_OK) on success; negative MI_ERR_* for argument errors (nothing is
+ * written); positive = the hipError_t that failed.  mi_last_error() describes the most recent
+ * failure on the calling thread.  (The reference returns void and asserts on CUDA errors,
+ * kernels/imageTools.cu:97-105; the C++ shims keep that behaviour.)
+ *
+ * Border convention: the stencil filters write their result only on
+ * {1<=x<=W-2, 1<=y<=H-2} like the reference (imageTools.cu:260,291,317) and write RGBA
+ * (0,0,0,0) elsewhere (the reference leaves fresh device memory there); neighbours are
+ * addressed by the reference's flat index (y+ky)*W+(x+kx); a flat index outside the image
+ * reads 0.
+ */
+#ifndef MI_IMAGETOOLS_H
+#define MI_IMAGETOOLS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_ERR_INVALID_ARG (-1)   /* null pointer, non-positive size, W<3 or H<3 for a stencil */
+#define MI_ERR_BAD_KERNEL_SIZE (-2) /* even, non-positive or too large kernel size */
+#define MI_ERR_UNSUPPORTED (-3)   /* a shape this build has no kernel for */
+#define MI_ERR_OVERLAP (-4)       /* device-tier in/out buffers overlap */
+#define MI_ERR_IO (-5)            /* file could not be written */
+
+#define MI_MAX_KERNEL_SIZE 31
+
+/* ---------------------------------------------------------------- library */
+
+int mi_version(void);
+const char *mi_last_error(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int mi_device_count(void);
+
+/* ---------------------------------------------------------------- device tier
+ * All device-tier filters process `batch` frames of w x h pixels stored back to back. */
+
+/* imageLoad / imageWrite kernels (imageTools.cu:107-132): byte stream <-> uchar4, a copy. */
+int mi_image_load_dev(const void *d_bytes, void *d_pixels, size_t n_pixels, void *stream);
+int mi_image_write_dev(void *d_bytes, const void *d_pixels, int w, int h, void *stream);
+
+/* imageGrayScale (imageTools.cu:217-231): every pixel, out=(g,g,g,A_in),
+ * g = trunc(fma(.114,B, fma(.299,R, .587*G))) in fp32. */
+int mi_grayscale_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, void *stream);
+
+/* imageSobelEdge (imageTools.cu:255-285): 3x3 Sobel on the .x channel, out=(m,m,m,255). */
+int mi_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, void *stream);
+
+/* imageGaussianBlur + generateGaussianKernal (imageTools.cu:287-311, 362-385).
+ * mode MI_GAUSS_SEPARABLE: row pass then column pass with 1-D weights (max |delta| <= 1 LSB
+ *   against the reference's direct 2-D sum, which truncates float->u8, imageTools.cu:306-308);
+ * mode MI_GAUSS_DIRECT: the reference's k x k sum in its own order, bit-exact, slower. */
+#define MI_GAUSS_SEPARABLE 0
+#define MI_GAUSS_DIRECT 1
+int mi_gaussian_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,
+                         float sigma, int mode, void *stream);
+
+/* imageMeanBlur (imageTools.cu:313-340); the reference wrapper fixes kernel_size=3 (:806). */
+int mi_meanblur_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,
+                         void *stream);
+
+/* Median blur, kernel_size 3 or 5.  README.md:3 of the reference advertises it; the reference
+ * has no code for it, so its semantics are this build's (per-channel median of the k x k flat
+ * taps on the same write set, alpha 255). */
+int mi_medianblur_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch,
+                           int kernel_size, void *stream);
+
+/* Row-strip variants for one image of w x h_total pixels split over several devices.
+ * d_in holds global rows [in_row0, in_row0+in_rows) (the strip plus its halo), d_out receives
+ * global rows [y_begin, y_end) starting at its row 0.  The halo must cover rows
+ * [y_begin-r-1, y_end+r+1) clipped to the image (r = kernel_size/2; the extra row is the
+ * flat-index wrap, needed only for r>1).  filter: one of MI_FILTER_*.  param_i = kernel size
+ * (ignored by gray/Sobel), param_f = sigma (Gaussian only). */
+#define MI_FILTER_GRAYSCALE 0
+#define MI_FILTER_SOBEL 1
+#define MI_FILTER_GAUSSIAN 2
+#define MI_FILTER_MEAN 3
+#define MI_FILTER_MEDIAN 4
+#define MI_FILTER_GAUSSIAN_DIRECT 5
+int mi_filter_strip_u8x4_dev(int filter, const void *d_in, void *d_out, int w, int h_total,
+                             int in_row0, int in_rows, int y_begin, int y_end, int param_i,
+                             float param_f, void *stream);
+/* Rows of halo a strip needs above and below for `filter` (0 for grayscale). */
+int mi_filter_halo_rows(int filter, int param_i);
+
+/* Synthetic input generator used by the benchmarks and tests (not in the reference):
+ * pixel i of stream `seed` = low 32 bits of splitmix64(seed*0x9E3779B97F4A7C15 + i), alpha 255. */
+int mi_synth_u8x4_dev(void *d_out, uint64_t seed, uint64_t first_idx, uint64_t count,
+                      void *stream);
+
+/* Sobel magnitude of s = Gx^2+Gy^2 for s in [0,count) as the device kernel computes it
+ * (uint8 per entry); lets a test sweep every reachable s.  Debug aid, not in the reference. */
+int mi_debug_sobel_mag_table_dev(void *d_out_u8, uint32_t count, void *stream);
+
+/* ---------------------------------------------------------------- FFT path (device tier)
+ * Complex planes are interleaved fp32 (re,im), `rows` x `cols`, row-major (cufftComplex). */
+
+/* uchar4ToCufftComplex (imageTools.cu:506-515): three planes (R,G,B), each (float(c), 0). */
+int mi_u8_to_complex_dev(const void *d_in, void *d_red, void *d_green, void *d_blue, int w, int h,
+                         void *stream);
+/* cufftExecC2C (imageTools.cu:690-701, 741-751): unnormalised 2-D complex DFT, out of place or
+ * in place, `batch` planes back to back.  direction -1 forward, +1 inverse.  rows and cols must
+ * be powers of two in [2, 8192] in this build. */
+#define MI_FFT_FORWARD (-1)
+#define MI_FFT_INVERSE (+1)
+int mi_fft2d_c2c_f32_dev(const void *d_in, void *d_out, int rows, int cols, int batch,
+                         int direction, void *stream);
+/* fftShift (imageTools.cu:564-583), in place. */
+int mi_fftshift_dev(void *d_data, int w, int h, void *stream);
+/* highpassFilter (imageTools.cu:530-549), in place, on a shifted spectrum. */
+int mi_highpass_dev(void *d_data, int w, int h, float cutoff, void *stream);
+/* NormalizeAndZeroImaginary (imageTools.cu:551-562), in place. */
+int mi_normalize_zero_imag_dev(void *d_data, int w, int h, void *stream);
+/* ComplexRGBToUchar (imageTools.cu:517-527) with the cast defined as saturate. */
+int mi_complex_to_u8_dev(const void *d_red, const void *d_green, const void *d_blue, void *d_out,
+                         int w, int h, void *stream);
+/* findMinMax (imageTools.cu:416-454): d_minmax receives {min, max} (2 floats). */
+int mi_minmax_f32_dev(const void *d_img, size_t n, void *d_minmax, void *stream);
+/* floatToUchar4 (imageTools.cu:458-471) after scaling by (v-min)/(max-min)*255. */
+int mi_normalize_to_u8_dev(const void *d_img, void *d_out, size_t n, const void *d_minmax,
+                           void *stream);
+
+/* ---------------------------------------------------------------- host tier
+ * Host pointers, blocking; replaces the reference wrapper of the same name. */
+
+/* imageLoadWrapper (imageTools.cu:158-183) */
+int mi_image_load(const uint8_t *bytes, uint8_t *pixels, size_t n_pixels);
+/* imageWriteWrapper (imageTools.cu:134-156): always writes a PNG, whatever the extension. */
+int mi_image_write(const char *filename, const uint8_t *pixels, int w, int h);
+/* imageGrayScaleWrapper (imageTools.cu:233-253) */
+int mi_grayscale_u8x4(const uint8_t *in, uint8_t *out, int w, int h);
+/* imageSobelEdgeWrapper (imageTools.cu:342-360) */
+int mi_sobel_u8x4(const uint8_t *in, uint8_t *out, int w, int h);
+/* imageGaussianBlurWrapper (imageTools.cu:478-502) */
+int mi_gaussian_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_size, float sigma,
+                     int mode);
+/* imageMeanBlurWrapper (imageTools.cu:794-812) with its hard-coded 3 as a parameter */
+int mi_meanblur_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_size);
+/* Median blur (README.md:3; no reference code) */
+int mi_medianblur_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_size);
+/* imageFFTImageGenerate (imageTools.cu:633-791) without its debug means; cutoff is the
+ * reference's hard-coded 10.0f (:716). */
+int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);
+/* generateGaussianKernal (imageTools.cu:362-385): fills out[kernel_size^2] on the host. */
+int mi_gaussian_kernel(int kernel_size, float sigma, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_IMAGETOOLS_H */

@@ -1,0 +1,276 @@
+"""GPU parity: the HIP path (through the C ABI in libmi_imagetools.so) against the CPU oracle on
+the same seeded inputs.  Bar: bit-exact for grayscale, Sobel, mean, median and the direct
+Gaussian; max |delta| <= 1 LSB for the separable Gaussian (the reference truncates float->u8,
+kernels/imageTools.cu:306-308, so a different summation order flips LSBs; BASELINE.json)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from cudaimageprocessing_amd import _lib, ops, synth as S  # noqa: E402
+
+GAUSS_TOL = 1   # LSB, separable mode
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+SIZES = [(64, 48), (67, 45), (3, 3), (4, 3), (5, 7), (256, 16), (250, 33), (1000, 37), (1021, 40), (516, 130)]
+PATTERNS = ["random", "natural", "binary", "checker", "gradient", "impulse", "constant"]
+
+
+def make(kind, w, h, seed):
+    return S.synth_image(seed, w, h) if kind == "random" else S.pattern_image(kind, w, h, seed)
+
+
+# ------------------------------------------------------------------ generator
+def test_device_synth_matches_host(dev, golden):
+    d = host(ops.synth(5, 131, 77))
+    assert np.array_equal(d, golden.synth(5, 131, 77))
+    b = host(ops.synth(1000, 64, 32, batch=3))
+    assert np.array_equal(b.reshape(-1, 4), golden.synth(1000, 64, 96).reshape(-1, 4))
+
+
+# ------------------------------------------------------------------ grayscale
+def test_grayscale_all_rgb_triples(dev, golden):
+    """Every one of the 2^24 (R,G,B) inputs, as a 4096x4096 image."""
+    idx = np.arange(1 << 24, dtype=np.uint32)
+    img = np.empty((1 << 24, 4), np.uint8)
+    img[:, 0] = idx >> 16
+    img[:, 1] = (idx >> 8) & 255
+    img[:, 2] = idx & 255
+    img[:, 3] = (idx * 7) & 255
+    out = host(ops.grayscale(to_dev(img.reshape(4096, 4096, 4), dev))).reshape(-1, 4)
+    table = golden.grayscale_table(True)
+    assert np.array_equal(out[:, 0], table)
+    assert np.array_equal(out[:, 1], table) and np.array_equal(out[:, 2], table)
+    assert np.array_equal(out[:, 3], img[:, 3])          # alpha passes through
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(1, 1), (2, 5), (1023, 3)])
+def test_grayscale_sizes(dev, golden, w, h):
+    img = S.synth_image(w * 31 + h, w, h)
+    img[..., 3] = img[..., 1]
+    assert np.array_equal(host(ops.grayscale(to_dev(img, dev))), golden.grayscale(img))
+
+
+# ------------------------------------------------------------------ Sobel
+def test_sobel_magnitude_every_reachable_sum(dev):
+    n = 2 * 1020 * 1020 + 1
+    got = host(ops.sobel_mag_table(n))
+    s = np.arange(n, dtype=np.int64)
+    expect = np.minimum(255, np.floor(np.sqrt(s.astype(np.float64)))).astype(np.int64)
+    # float64 sqrt of an integer < 2^53 floors correctly except possibly at perfect squares: fix up
+    expect = np.where((expect + 1) ** 2 <= s, expect + 1, expect)
+    expect = np.where(expect ** 2 > s, expect - 1, expect)
+    expect = np.minimum(255, expect)
+    assert np.array_equal(got.astype(np.int64), expect)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("kind", ["random", "natural", "binary", "gradient"])
+def test_sobel(dev, golden, w, h, kind):
+    img = make(kind, w, h, 3)
+    assert np.array_equal(host(ops.sobel(to_dev(img, dev))), golden.sobel(img))
+
+
+# ------------------------------------------------------------------ mean
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("kind", ["random", "constant", "binary"])
+def test_mean3(dev, golden, w, h, kind):
+    img = make(kind, w, h, 4)
+    assert np.array_equal(host(ops.mean_blur(to_dev(img, dev), 3)), golden.meanblur(img, 3))
+
+
+@pytest.mark.parametrize("k", [1, 5, 7, 11])
+def test_mean_other_sizes(dev, golden, k):
+    for (w, h) in ((67, 45), (256, 16), (5, 7)):
+        img = S.synth_image(k, w, h)
+        assert np.array_equal(host(ops.mean_blur(to_dev(img, dev), k)), golden.meanblur(img, k))
+
+
+# ------------------------------------------------------------------ median
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("kind", PATTERNS)
+def test_median3(dev, golden, w, h, kind):
+    img = make(kind, w, h, 5)
+    assert np.array_equal(host(ops.median_blur(to_dev(img, dev), 3)), golden.medianblur(img, 3))
+
+
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (5, 7), (3, 3), (250, 33)])
+@pytest.mark.parametrize("kind", ["random", "binary", "natural", "checker"])
+def test_median5(dev, golden, w, h, kind):
+    img = make(kind, w, h, 6)
+    assert np.array_equal(host(ops.median_blur(to_dev(img, dev), 5)), golden.medianblur(img, 5))
+
+
+# ------------------------------------------------------------------ Gaussian
+@pytest.mark.parametrize("k,sigma", [(3, 7.0), (5, 1.0), (7, 1.5), (9, 2.0), (11, 2.0), (13, 3.0), (15, 2.5)])
+def test_gaussian_separable_within_1_lsb(dev, golden, k, sigma):
+    worst, flips, total = 0, 0, 0
+    for (w, h) in SIZES:
+        for kind in ("random", "natural", "constant"):
+            img = make(kind, w, h, k)
+            got = host(ops.gaussian_blur(to_dev(img, dev), k, sigma)).astype(np.int16)
+            ref = golden.gaussian(img, k, sigma).astype(np.int16)
+            d = np.abs(got - ref)
+            worst = max(worst, int(d.max()))
+            flips += int((d != 0).sum())
+            total += d.size
+            assert np.array_equal(got[..., 3], ref[..., 3])
+            # border is exactly zero in both
+            assert (got[0] == 0).all() and (got[:, 0] == 0).all() and (got[-1] == 0).all() and (got[:, -1] == 0).all()
+    print(f"gaussian k={k} sigma={sigma}: max|delta|={worst}, {flips}/{total} bytes differ")
+    assert worst <= GAUSS_TOL
+
+
+@pytest.mark.parametrize("k,sigma", [(1, 0.5), (3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)])
+def test_gaussian_direct_is_bit_exact(dev, golden, k, sigma):
+    for (w, h) in ((67, 45), (64, 48), (5, 7), (256, 16)):
+        img = S.synth_image(100 + k, w, h)
+        got = host(ops.gaussian_blur(to_dev(img, dev), k, sigma, direct=True))
+        assert np.array_equal(got, golden.gaussian(img, k, sigma))
+
+
+# ------------------------------------------------------------------ batches, strips, chain
+def test_batch_equals_per_frame(dev, golden):
+    w, h, b = 130, 37, 5
+    frames = np.stack([S.synth_image(1000 + f, w, h) for f in range(b)])
+    d = to_dev(frames, dev)
+    for name, fn, ref in (
+        ("gray", lambda t: ops.grayscale(t), golden.grayscale),
+        ("sobel", lambda t: ops.sobel(t), golden.sobel),
+        ("mean", lambda t: ops.mean_blur(t, 3), lambda x: golden.meanblur(x, 3)),
+        ("median3", lambda t: ops.median_blur(t, 3), lambda x: golden.medianblur(x, 3)),
+        ("median5", lambda t: ops.median_blur(t, 5), lambda x: golden.medianblur(x, 5)),
+        ("gauss_direct", lambda t: ops.gaussian_blur(t, 5, 1.0, direct=True), lambda x: golden.gaussian(x, 5, 1.0)),
+    ):
+        out = host(fn(d))
+        for f in range(b):
+            assert np.array_equal(out[f], ref(frames[f])), (name, f)
+    g = host(ops.gaussian_blur(d, 5, 1.0)).astype(np.int16)
+    for f in range(b):
+        assert np.abs(g[f] - golden.gaussian(frames[f], 5, 1.0).astype(np.int16)).max() <= GAUSS_TOL
+
+
+STRIP_FILTERS = [
+    (_lib.FILTER_GRAYSCALE, 0, 0.0), (_lib.FILTER_SOBEL, 3, 0.0), (_lib.FILTER_MEAN, 3, 0.0),
+    (_lib.FILTER_MEDIAN, 3, 0.0), (_lib.FILTER_MEDIAN, 5, 0.0), (_lib.FILTER_GAUSSIAN, 5, 1.0),
+    (_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_GAUSSIAN_DIRECT, 5, 1.0), (_lib.FILTER_MEAN, 7, 0.0),
+]
+
+
+def run_full(filt, img_d, k, sigma):
+    if filt == _lib.FILTER_GRAYSCALE:
+        return ops.grayscale(img_d)
+    if filt == _lib.FILTER_SOBEL:
+        return ops.sobel(img_d)
+    if filt == _lib.FILTER_MEAN:
+        return ops.mean_blur(img_d, k)
+    if filt == _lib.FILTER_MEDIAN:
+        return ops.median_blur(img_d, k)
+    return ops.gaussian_blur(img_d, k, sigma, direct=(filt == _lib.FILTER_GAUSSIAN_DIRECT))
+
+
+@pytest.mark.parametrize("filt,k,sigma", STRIP_FILTERS)
+@pytest.mark.parametrize("w,h,parts", [(64, 64, 4), (67, 45, 3), (256, 40, 2)])
+def test_strips_stitch_to_full_image(dev, filt, k, sigma, w, h, parts):
+    """Row strips with halo (the multi-GPU decomposition) are bit-identical to one full launch."""
+    img = S.synth_image(40 + k, w, h)
+    img_d = to_dev(img, dev)
+    full = host(run_full(filt, img_d, k, sigma))
+    halo = ops.halo_rows(filt, k)
+    edges = [h * p // parts for p in range(parts + 1)]
+    pieces = []
+    for p in range(parts):
+        y0, y1 = edges[p], edges[p + 1]
+        r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+        strip = img_d[r0:r1].contiguous()
+        out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+        ops.filter_strip(filt, strip, out, w, h, r0, y0, y1, k, sigma)
+        pieces.append(host(out))
+    assert np.array_equal(np.concatenate(pieces), full)
+
+
+def test_chain_4k_frame_against_oracle(dev, golden):
+    """BASELINE.json config 2 at full size: gray -> Gaussian 5x5 -> median 3x3 -> Sobel."""
+    w, h = 3840, 2160
+    img_d = ops.synth(2, w, h)
+    img = host(img_d)
+    assert np.array_equal(img, S.synth_image(2, w, h))
+    a, b, c, d = [host(t) for t in ops.filter_chain(img_d)]
+    ga = golden.grayscale(img, threads=8)
+    assert np.array_equal(a, ga)
+    # stage by stage on the device's own previous stage, so a +-1 in the Gaussian does not leak
+    gb = golden.gaussian(a, 5, 1.0, threads=8)
+    assert np.abs(b.astype(np.int16) - gb.astype(np.int16)).max() <= GAUSS_TOL
+    assert np.array_equal(c, golden.medianblur(b, 3, threads=8))
+    assert np.array_equal(d, golden.sobel(c, threads=8))
+
+
+def test_large_batch_properties(dev):
+    """Size-independent properties on a batch too large for the oracle: a batch result equals the
+    same frames processed one by one, and a constant image stays constant inside the write set."""
+    w, h, b = 1920, 1080, 8
+    frames = ops.synth(1000, w, h, batch=b)
+    for fn in (ops.grayscale, ops.sobel, lambda t: ops.median_blur(t, 3), lambda t: ops.gaussian_blur(t, 5, 1.0),
+               lambda t: ops.mean_blur(t, 3)):
+        whole = fn(frames)
+        for f in (0, 3, 7):
+            assert torch.equal(whole[f], fn(frames[f].contiguous()))
+    const = torch.full((h, w, 4), 77, dtype=torch.uint8, device=dev)
+    m = ops.median_blur(const, 3)
+    assert int(m[2:-2, 2:-2, :3].min()) == 77 and int(m[2:-2, 2:-2, :3].max()) == 77
+    assert int(ops.sobel(const)[2:-2, 2:-2, 0].max()) == 0
+
+
+# ------------------------------------------------------------------ host tier (reference names)
+def test_host_tier_wrappers(dev, golden, tmp_path):
+    w, h = 131, 67
+    img = S.synth_image(77, w, h)
+    out = np.empty_like(img)
+    ops.imageGrayScaleWrapper(out, img, w, h)
+    assert np.array_equal(out, golden.grayscale(img))
+    ops.imageSobelEdgeWrapper(out, img, w, h)
+    assert np.array_equal(out, golden.sobel(img))
+    ops.imageMeanBlurWrapper(out, img, w, h)
+    assert np.array_equal(out, golden.meanblur(img, 3))
+    ops.imageMedianBlurWrapper(out, img, w, h, 3)
+    assert np.array_equal(out, golden.medianblur(img, 3))
+    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0)        # the reference's call, main.cpp:41
+    assert np.abs(out.astype(np.int16) - golden.gaussian(img, 3, 7.0).astype(np.int16)).max() <= GAUSS_TOL
+    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0, direct=True)
+    assert np.array_equal(out, golden.gaussian(img, 3, 7.0))
+    # in place, as main.cpp:38-43 calls every wrapper with (img, img, ...)
+    alias = img.copy()
+    ops.imageSobelEdgeWrapper(alias, alias, w, h)
+    assert np.array_equal(alias, golden.sobel(img))
+    loaded = np.empty(w * h * 4, np.uint8)
+    ops.imageLoadWrapper(img.reshape(-1), loaded, w * h)
+    assert np.array_equal(loaded, img.reshape(-1))
+
+
+def test_device_load_write_copy(dev):
+    img = ops.synth(8, 123, 45)
+    flat = ops.image_write(img)
+    assert torch.equal(flat, img.reshape(-1))
+    back = ops.image_load(flat)
+    assert torch.equal(back, img.reshape(-1))
+    odd = flat[1:1 + 4 * 99]                     # a view: unaligned source pointer, byte path
+    assert torch.equal(ops.image_load(odd), odd)

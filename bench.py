@@ -148,14 +148,14 @@ def main():
                          "avg_launch_ms": per_stage[worst]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            v, dt = cpu_baseline(frames=1, threads=1)
+            v, dt = cpu_baseline(frames=8, threads=1)
             out["cpu_baseline"] = {"value": v, "unit": "MP/s", "cores": 1, "kind": "port",
-                                   "sample": f"the same 4-stage chain on 1 synthetic {W}x{H} frame, "
+                                   "sample": f"the same 4-stage chain on 8 synthetic {W}x{H} frames, "
                                              f"oracle/golden.c single thread, {dt:.1f} s"}
             nthr = min(16, os.cpu_count() or 1)
-            v2, dt2 = cpu_baseline(frames=2, threads=nthr)
+            v2, dt2 = cpu_baseline(frames=16, threads=nthr)
             out["cpu_baseline_threads"] = {"value": v2, "unit": "MP/s", "cores": nthr, "kind": "port",
-                                           "sample": f"2 frames, row bands on {nthr} threads, {dt2:.1f} s"}
+                                           "sample": f"16 frames, row bands on {nthr} threads, {dt2:.1f} s"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

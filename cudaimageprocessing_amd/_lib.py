@@ -68,6 +68,12 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m cudaimageprocessing_amd.build` "
                 "(hipcc, gfx950).  This package has no CPU fallback.")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (soname
+        # libamdhip64.so.7, the one this library asks for).  Loaded after torch, the library
+        # binds to that copy; loaded before it, the process would end up with two runtimes and
+        # the second one finds no device.  torch is this package's device-memory/stream
+        # plumbing anyway, so import it first.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(handle, name)

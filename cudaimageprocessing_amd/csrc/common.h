@@ -28,6 +28,7 @@ struct Geo {
     int rows_per_band;    // rows one wave marches over
     int bands, strips;    // per frame
     int total_waves;      // batch * bands * strips
+    int xcd_remap;        // 1: give each XCD a contiguous run of blocks
     i64 N;                // W*H
     i64 in_lo, in_hi;     // flat pixel indices [in_lo, in_hi) present in `in`
     i64 in_origin;        // flat index of in[0]
@@ -63,9 +64,10 @@ MI_DEV u32 pk_sub(u32 a, u32 b)
 // Four pixels at flat index f..f+3 of the global image; pixels outside the image (or outside
 // the rows present in `in`) read 0.  ALIGNED: every f passed is a multiple of 4 and `in` is
 // 16-byte aligned, so the fast path is one aligned dwordx4 load.
-template <bool ALIGNED>
+template <int POL>
 MI_DEV u32x4 load_px4(const u32* __restrict__ in, const Geo& g, i64 f)
 {
+    constexpr bool ALIGNED = POL & 1;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (f >= g.in_lo && f + 4 <= g.in_hi) {
         const u32* p = in + (f - g.in_origin);
@@ -82,12 +84,15 @@ MI_DEV u32x4 load_px4(const u32* __restrict__ in, const Geo& g, i64 f)
 }
 
 // Store four output pixels of row y at columns cx..cx+3 (columns >= W are dropped).
-template <bool ALIGNED>
+template <int POL>
 MI_DEV void store_px4(u32* __restrict__ out, const Geo& g, int y, int cx, u32x4 v)
 {
+    constexpr bool ALIGNED = POL & 1;
     u32* p = out + ((i64)y * g.W + cx - g.out_origin);
-    if (ALIGNED) {
-        *reinterpret_cast<u32x4*>(p) = v;   // W%4==0 and cx%4==0: cx<W implies cx+4<=W
+    if (ALIGNED) {   // W%4==0 and cx%4==0: cx<W implies cx+4<=W
+        // streaming store: the output is not read again by this kernel, keep the caches for
+        // the input rows that neighbouring waves share
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
     } else if (cx + 4 <= g.W) {
         *reinterpret_cast<u32x4_u*>(p) = v;
     } else {
@@ -111,7 +116,7 @@ MI_DEV WaveJob wave_job(const Geo& g)
     const int waves_per_block = blockDim.x >> 6;
     const u32 nblk = gridDim.x, b = blockIdx.x;
     const u32 q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    const u32 logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const u32 logical = g.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
     int wid = (int)logical * waves_per_block + (int)(threadIdx.x >> 6);
     wid = __builtin_amdgcn_readfirstlane(wid);
     WaveJob j;
@@ -126,3 +131,88 @@ MI_DEV WaveJob wave_job(const Geo& g)
 
 // x-mask helper: 0xFFFFFFFF where column x lies in the reference's write set [1, W-2].
 MI_DEV u32 xmask(int x, int W) { return (x >= 1 && x <= W - 2) ? 0xFFFFFFFFu : 0u; }
+
+// Rows of a wave's band in marching order.  Even bands march down, odd bands march up, so two
+// vertically adjacent bands reach their common boundary at the same time (both at the start
+// or both at the end of their march): the halo rows they both need are then fetched from HBM
+// once and hit in the XCD's L2 for the second wave.  step i in [0, n) is output row row(i);
+// the stencil needs input rows row(i-R) .. row(i+R).
+struct March {
+    int ys, dir, n;
+    MI_DEV int row(int i) const { return ys + dir * i; }
+};
+
+MI_DEV March make_march(const Geo& g, const WaveJob& j)
+{
+    const int y0 = g.y_begin + j.band * g.rows_per_band;
+    const int y1 = min(y0 + g.rows_per_band, g.y_end);
+    March m;
+    m.n = y1 - y0;
+    m.dir = (j.band & 1) ? -1 : 1;
+    m.ys = (j.band & 1) ? y1 - 1 : y0;
+    return m;
+}
+
+// Row I/O of one wave.  POL 0 (any width/alignment): per-lane 64-bit addresses with explicit
+// range checks (load_px4/store_px4).  POL 1 (width % 4 == 0, 16-byte-aligned buffers): buffer
+// instructions through two wave-uniform resource descriptors.  The hardware range check then
+// does the work of the reference-UB conventions for free -- a tap whose flat index lies outside
+// the image (or outside the rows present) reads 0 -- and of store predication: a lane that must
+// not write is given an out-of-range offset.  With no branches around the memory operations the
+// compiler counts them exactly (s_waitcnt vmcnt(1) in the row loop), so a wave never waits for
+// its own stores.  Everything is a multiple of 4 pixels in this mode, so a 16-byte access is
+// never partly in range.
+template <int POL>
+struct RowIO;
+
+template <>
+struct RowIO<0> {
+    const u32* in;
+    u32* out;
+    const Geo* g;
+    int cx;
+    bool productive;
+    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g_, const WaveJob& j, const March&, int cx0, int margin)
+        : in(in_ + (i64)j.frame * g_.in_frame_stride), out(out_ + (i64)j.frame * g_.out_frame_stride), g(&g_)
+    {
+        cx = cx0 + 4 * j.lane;
+        productive = j.lane >= margin && j.lane < 64 - margin && cx < g_.W;
+    }
+    MI_DEV u32x4 load(int row) const { return load_px4<0>(in, *g, (i64)row * g->W + cx); }
+    MI_DEV void store(int y, u32x4 v) const { if (productive) store_px4<0>(out, *g, y, cx, v); }
+};
+
+template <>
+struct RowIO<1> {
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int in_off;    // byte offset of this lane's 4 pixels in row `row0`, relative to rin's base
+    u32 out_off;   // same for rout; 0x80000000 (out of range) for lanes that must not store
+    int row0, ylo, pitch;
+    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g, const WaveJob& j, const March& m, int cx0, int margin)
+    {
+        const u32* in = in_ + (i64)j.frame * g.in_frame_stride;
+        u32* out = out_ + (i64)j.frame * g.out_frame_stride;
+        ylo = m.dir > 0 ? m.ys : m.ys - (m.n - 1);
+        row0 = ylo - 16;                       // any row at or above the first one loaded
+        pitch = g.W * 4;
+        const i64 fmin = (i64)row0 * g.W + cx0;          // lowest flat index this wave can touch
+        const i64 base = fmin > g.in_lo ? fmin : g.in_lo;
+        i64 bytes = (g.in_hi - base) * 4;
+        bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFF00LL ? 0x7FFFFF00LL : bytes);
+        rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
+        in_off = (int)((fmin - base) * 4) + 16 * j.lane;
+        const i64 obase = (i64)ylo * g.W;
+        rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (obase - g.out_origin)), 0, m.n * pitch, 0x00020000);
+        const int cx = cx0 + 4 * j.lane;
+        const bool productive = j.lane >= margin && j.lane < 64 - margin && cx < g.W;
+        out_off = productive ? (u32)(cx * 4) : 0x80000000u;
+    }
+    MI_DEV u32x4 load(int row) const
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, (row - row0) * pitch + in_off, 0, 0);
+    }
+    MI_DEV void store(int y, u32x4 v) const
+    {   // aux 2 = nt: streaming store, the output is not read again by this kernel
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, (u32)((y - ylo) * pitch) + out_off, 0, 2);
+    }
+};

@@ -23,34 +23,43 @@ MI_DEV u32 gray_px(u32 p)
     return (u32)v * 0x010101u + (p & 0xFF000000u);
 }
 
-// Flat over all pixels: one 16-byte load and one 16-byte store per lane per step, UNROLL
-// independent steps in flight per lane.
-template <bool ALIGNED, int UNROLL>
+// Flat over all pixels.  Each block owns V*256 consecutive 16-byte groups (4 pixels each) and
+// each lane V of them; the grid covers the image once (no grid-stride loop): on MI355X a
+// streaming pass runs fastest when the dispatcher walks the buffer front to back
+// (tools/membench.hip: 6.0-6.4 TB/s against 4.2 TB/s for a 2048-block grid-stride loop).
+template <int POL, int V>
 __global__ __launch_bounds__(256) void gray_kernel(const u32* __restrict__ in,
                                                    u32* __restrict__ out, i64 n_px)
 {
-    const i64 groups = (n_px + 3) >> 2;  // groups of 4 pixels
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    i64 gidx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; gidx + (UNROLL - 1) * stride < groups - 1; gidx += UNROLL * stride) {
-        u32x4 v[UNROLL];
+    constexpr bool ALIGNED = POL & 1, NT = POL & 2;
+    const i64 groups = (n_px + 3) >> 2;  // groups of 4 pixels; the last one may be ragged
+    const i64 base = (i64)blockIdx.x * (256 * V) + threadIdx.x;
+    u32x4 v[V];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const u32* p = in + 4 * (gidx + u * stride);
-            v[u] = ALIGNED ? *reinterpret_cast<const u32x4*>(p)
-                           : (u32x4)(*reinterpret_cast<const u32x4_u*>(p));
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            u32x4 o = {gray_px(v[u].x), gray_px(v[u].y), gray_px(v[u].z), gray_px(v[u].w)};
-            u32* q = out + 4 * (gidx + u * stride);
-            if (ALIGNED) *reinterpret_cast<u32x4*>(q) = o;
-            else *reinterpret_cast<u32x4_u*>(q) = o;
+    for (int u = 0; u < V; u++) {
+        const i64 gi = base + u * 256;
+        if (gi < groups - 1) {
+            const u32* p = in + 4 * gi;
+            if (ALIGNED) v[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+                                   : *reinterpret_cast<const u32x4*>(p);
+            else v[u] = *reinterpret_cast<const u32x4_u*>(p);
         }
     }
-    for (; gidx < groups; gidx += stride) {  // remainder, including the ragged last group
-        const i64 base = 4 * gidx;
-        for (int k = 0; k < 4 && base + k < n_px; k++) out[base + k] = gray_px(in[base + k]);
+#pragma unroll
+    for (int u = 0; u < V; u++) {
+        const i64 gi = base + u * 256;
+        if (gi < groups - 1) {
+            const u32x4 o = {gray_px(v[u].x), gray_px(v[u].y), gray_px(v[u].z), gray_px(v[u].w)};
+            u32* q = out + 4 * gi;
+            if (ALIGNED) {
+                if (NT) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(q));
+                else *reinterpret_cast<u32x4*>(q) = o;
+            } else {
+                *reinterpret_cast<u32x4_u*>(q) = o;
+            }
+        } else if (gi == groups - 1) {
+            for (i64 k = 4 * gi; k < n_px; k++) out[k] = gray_px(in[k]);
+        }
     }
 }
 
@@ -74,29 +83,29 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
     r23 = __builtin_amdgcn_perm(p.w, p.z, 0x0c040c00u);
 }
 
-template <bool ALIGNED>
+template <int POL, int M = 1>
 __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
     const WaveJob j = wave_job(g);
     if (!j.valid) return;
-    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
+    constexpr int OUTW = 4 * (64 - 2 * M);
     const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const int y0 = g.y_begin + j.band * g.rows_per_band;
-    const int y1 = min(y0 + g.rows_per_band, g.y_end);
-    in += (i64)j.frame * g.in_frame_stride;
-    out += (i64)j.frame * g.out_frame_stride;
-    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
     const u32 xm0 = xmask(cx, g.W), xm1 = xmask(cx + 1, g.W), xm2 = xmask(cx + 2, g.W),
               xm3 = xmask(cx + 3, g.W);
 
     u32 t01, t23, m01, m23, b01, b23;
-    red_pairs(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), t01, t23);
-    red_pairs(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), m01, m23);
-    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
-    for (int y = y0; y < y1; y++) {
+    // t = oldest row of the window, b = newest.  Marching up swaps their roles, which only flips
+    // the sign of Gy; Gx^2 + Gy^2 does not change.
+    red_pairs(io.load(mch.row(-1)), t01, t23);
+    red_pairs(io.load(mch.row(0)), m01, m23);
+    u32x4 nxt = io.load(mch.row(1));
+    for (int i = 0; i < mch.n; i++) {
+        const int y = mch.row(i);
         red_pairs(nxt, b01, b23);
-        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);  // prefetch the next row
+        nxt = io.load(mch.row(i + 2));  // prefetch the next row
         const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
         const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
         const u32 D01 = pk_sub(b01, t01), D23 = pk_sub(b23, t23);
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
         o.y = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P1), __builtin_bit_cast(s16x2, P1), 0, false)) * 0x010101u | 0xFF000000u) & xm1 & rowm;
         o.z = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P2), __builtin_bit_cast(s16x2, P2), 0, false)) * 0x010101u | 0xFF000000u) & xm2 & rowm;
         o.w = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P3), __builtin_bit_cast(s16x2, P3), 0, false)) * 0x010101u | 0xFF000000u) & xm3 & rowm;
-        if (productive) store_px4<ALIGNED>(out, g, y, cx, o);
+        io.store(y, o);
         t01 = m01; t23 = m23; m01 = b01; m23 = b23;
     }
 }
@@ -151,7 +160,7 @@ MI_DEV u32 div9_pack(u32 lo, u32 hi)
     return qr | qg | qb | 0xFF000000u;
 }
 
-template <bool ALIGNED>
+template <int POL>
 __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
@@ -159,11 +168,8 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     if (!j.valid) return;
     constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
     const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const int y0 = g.y_begin + j.band * g.rows_per_band;
-    const int y1 = min(y0 + g.rows_per_band, g.y_end);
-    in += (i64)j.frame * g.in_frame_stride;
-    out += (i64)j.frame * g.out_frame_stride;
-    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
 
     // horizontal 3-sums of one row, per pixel, as (lo, hi) packed pairs
@@ -183,12 +189,13 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    hsum(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), tl, th);
-    hsum(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), ml, mh);
-    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
-    for (int y = y0; y < y1; y++) {
+    hsum(io.load(mch.row(-1)), tl, th);
+    hsum(io.load(mch.row(0)), ml, mh);
+    u32x4 nxt = io.load(mch.row(1));
+    for (int i = 0; i < mch.n; i++) {
+        const int y = mch.row(i);
         hsum(nxt, bl, bh);
-        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);
+        nxt = io.load(mch.row(i + 2));
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
         u32 o[4];
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
             o[k] = div9_pack(sl, sh) & xm[k] & rowm;
             tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k];
         }
-        if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+        io.store(y, u32x4{o[0], o[1], o[2], o[3]});
     }
 }
 
@@ -219,7 +226,7 @@ MI_DEV u32 med3(u32 a, u32 b, u32 c)
     return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
 }
 
-template <bool ALIGNED>
+template <int POL>
 __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in,
                                                       u32* __restrict__ out, const Geo g)
 {
@@ -227,11 +234,8 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
     if (!j.valid) return;
     constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
     const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const int y0 = g.y_begin + j.band * g.rows_per_band;
-    const int y1 = min(y0 + g.rows_per_band, g.y_end);
-    in += (i64)j.frame * g.in_frame_stride;
-    out += (i64)j.frame * g.out_frame_stride;
-    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
 
     auto unpack4 = [&](u32x4 p, u32 (&l)[4], u32 (&h)[4]) {
@@ -240,12 +244,13 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    unpack4(load_px4<ALIGNED>(in, g, (i64)(y0 - 1) * g.W + cx), tl, th);
-    unpack4(load_px4<ALIGNED>(in, g, (i64)y0 * g.W + cx), ml, mh);
-    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + 1) * g.W + cx);
-    for (int y = y0; y < y1; y++) {
+    unpack4(io.load(mch.row(-1)), tl, th);
+    unpack4(io.load(mch.row(0)), ml, mh);
+    u32x4 nxt = io.load(mch.row(1));
+    for (int i = 0; i < mch.n; i++) {
+        const int y = mch.row(i);
         unpack4(nxt, bl, bh);
-        nxt = load_px4<ALIGNED>(in, g, (i64)(y + 2) * g.W + cx);
+        nxt = io.load(mch.row(i + 2));
         // sorted columns: index 0 = left neighbour's column 3, 1..4 = own, 5 = right's column 0
         u32 cl[6][2], cm[6][2], ch[6][2];   // [column][0=lo pair (R,B), 1=hi pair (G,A)]
 #pragma unroll
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
             o[k] = (r[0] | (r[1] << 8) | 0xFF000000u) & xm[k] & rowm;
             tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k];
         }
-        if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+        io.store(y, u32x4{o[0], o[1], o[2], o[3]});
     }
 }
 
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
 // rounding only: max |delta| = 1 LSB after truncation.
 struct GaussW { float w[16]; };
 
-template <int R, bool ALIGNED>
+template <int R, int POL>
 __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ in,
                                                         u32* __restrict__ out, const Geo g,
                                                         const GaussW gw)
@@ -301,11 +306,8 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
     const WaveJob j = wave_job(g);
     if (!j.valid) return;
     const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const int y0 = g.y_begin + j.band * g.rows_per_band;
-    const int y1 = min(y0 + g.rows_per_band, g.y_end);
-    in += (i64)j.frame * g.in_frame_stride;
-    out += (i64)j.frame * g.out_frame_stride;
-    const bool productive = j.lane >= M && j.lane < 64 - M && cx < g.W;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
 
     // Row pass: h[3*k+c] = sum_t w[t] * channel c of column (k - R + t), k = 0..3.
@@ -342,20 +344,22 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
     };
 
     float win[K][12];
-    // rows y0-R .. y0+R-1 fill slots 0 .. K-2
+    // input rows row(-R) .. row(R-1) fill slots 0 .. K-2 (the weights are symmetric, so the
+    // marching direction does not matter to the column pass)
 #pragma unroll
     for (int i = 0; i < K - 1; i++)
-        hrow(load_px4<ALIGNED>(in, g, (i64)(y0 - R + i) * g.W + cx), win[i]);
-    u32x4 nxt = load_px4<ALIGNED>(in, g, (i64)(y0 + R) * g.W + cx);
+        hrow(io.load(mch.row(i - R)), win[i]);
+    u32x4 nxt = io.load(mch.row(R));
 
-    for (int base = y0; base < y1; base += K) {
+    for (int base = 0; base < mch.n; base += K) {
 #pragma unroll
         for (int s = 0; s < K; s++) {
-            const int y = base + s;
-            if (y < y1) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
             // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
             hrow(nxt, win[(K - 1 + s) % K]);
-            nxt = load_px4<ALIGNED>(in, g, (i64)(y + R + 1) * g.W + cx);
+            nxt = io.load(mch.row(i + R + 1));
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -363,14 +367,18 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
                 float acc[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    float a = gw.w[0] * win[s % K][3 * k + c];
+                    // centre tap, then the symmetric pairs (w[t] == w[K-1-t]): the sum does not
+                    // depend on whether the band marches down or up, so any decomposition into
+                    // bands or strips gives bit-identical output
+                    float a = gw.w[R] * win[(s + R) % K][3 * k + c];
 #pragma unroll
-                    for (int t = 1; t < K; t++) a = __builtin_fmaf(gw.w[t], win[(s + t) % K][3 * k + c], a);
+                    for (int t = 0; t < R; t++)
+                        a = __builtin_fmaf(gw.w[t], win[(s + t) % K][3 * k + c] + win[(s + K - 1 - t) % K][3 * k + c], a);
                     acc[c] = a;
                 }
                 o[k] = ((u32)acc[0] | ((u32)acc[1] << 8) | ((u32)acc[2] << 16) | 0xFF000000u) & xm[k] & rowm;
             }
-            if (productive) store_px4<ALIGNED>(out, g, y, cx, u32x4{o[0], o[1], o[2], o[3]});
+            io.store(y, u32x4{o[0], o[1], o[2], o[3]});
             }
         }
     }
@@ -552,12 +560,18 @@ int filter_halo_rows(int filter, int ksize)
     }
 }
 
+// Launch KERNEL<..., POL>: POL 1 for 16-byte-aligned images whose width is a multiple of 4
+// (aligned dwordx4 accesses), POL 0 otherwise.
+#define MI_POLICY_CASES(pol, LAUNCH) \
+    if (pol) { LAUNCH(1); } else { LAUNCH(0); }
+
 template <int R>
-static void launch_gauss_sep(bool aligned, int grid, hipStream_t s, const u32* in, u32* out,
+static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out,
                              const Geo& g, const GaussW& gw)
 {
-    if (aligned) gauss_sep_kernel<R, true><<<grid, 256, 0, s>>>(in, out, g, gw);
-    else gauss_sep_kernel<R, false><<<grid, 256, 0, s>>>(in, out, g, gw);
+#define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+    MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
 }
 
 int launch_filter(const FilterArgs& a)
@@ -580,9 +594,10 @@ int launch_filter(const FilterArgs& a)
             u32* dst = out + (i64)f * out_frame;
             const bool al = ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
             const i64 groups = (n + 3) / 4;
-            const int grid = (int)std::max<i64>(1, std::min<i64>((groups + 256 * 4 - 1) / (256 * 4), grid_cap()));
-            if (al) gray_kernel<true, 4><<<grid, 256, 0, a.stream>>>(src, dst, n);
-            else gray_kernel<false, 4><<<grid, 256, 0, a.stream>>>(src, dst, n);
+            const i64 blocks = (groups + 255) / 256;   // one 16-byte group per lane
+            if (blocks > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "launch too large");
+            if (al) gray_kernel<3, 1><<<(int)blocks, 256, 0, a.stream>>>(src, dst, n);
+            else gray_kernel<0, 1><<<(int)blocks, 256, 0, a.stream>>>(src, dst, n);
         }
         return hip_status(hipGetLastError(), "grayscale kernel launch");
     }
@@ -604,7 +619,7 @@ int launch_filter(const FilterArgs& a)
     const bool mean_generic = a.filter == MI_FILTER_MEAN && a.ksize != 3;
     const bool median5 = a.filter == MI_FILTER_MEDIAN && a.ksize == 5;
     if (direct || mean_generic || median5) {
-        g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0;
+        g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {
             const int nb = std::min(65535, a.batch - f0);
             for (int r0 = 0; r0 < rows; r0 += 65535) {
@@ -631,45 +646,64 @@ int launch_filter(const FilterArgs& a)
     // wave-march kernels
     int margin = 1;
     if (a.filter == MI_FILTER_GAUSSIAN) margin = (a.ksize / 2 + 3) / 4;
+    if (a.filter == MI_FILTER_SOBEL && env_int("MI_SOBEL_M4", 0)) margin = 4;
     const int outw = 4 * (64 - 2 * margin);
     g.strips = (W + outw - 1) / outw;
+    // Rows per band.  Short bands keep the waves that run together on nearby rows, so the
+    // access stream stays close to a front-to-back sweep (measured on MI355X: 3x3 filters peak
+    // at 4-6 rows per band, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
+    // are shared with the neighbouring band through L2 (see March), not re-fetched from HBM.
+    // A taller band amortises the row pass of a wide Gaussian over more output rows.
     int rpb = env_int("MI_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
-        // enough waves to fill 256 CUs x 4 SIMDs several times over, bands as tall as that allows
-        rpb = 32;
-        while (rpb > 8 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < 8192) rpb >>= 1;
+        const int r = a.filter == MI_FILTER_GAUSSIAN ? a.ksize / 2 : 1;
+        rpb = r == 1 ? 6 : std::min(10 * r, 64);
+        while (rpb > 4 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < 4096) rpb >>= 1;
     }
+    // POL 1 addresses a band through 32-bit buffer offsets: keep a band under 1 GiB
+    rpb = std::max(1, std::min(rpb, (int)((1LL << 28) / W)));
     g.rows_per_band = rpb;
     g.bands = (rows + rpb - 1) / rpb;
     const i64 total = (i64)a.batch * g.bands * g.strips;
     if (total > 0x7fffffff / 64) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
     g.total_waves = (int)total;
+    g.xcd_remap = env_int("MI_XCD_REMAP", 1);
+    const int pol = aligned ? 1 : 0;
     const int grid = (int)((total + 3) / 4);
 
     switch (a.filter) {
     case MI_FILTER_SOBEL:
-        if (aligned) sobel_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
-        else sobel_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+    {
+#define MI_L(P) if (margin == 4) sobel_kernel<P, 4><<<grid, 256, 0, a.stream>>>(in, out, g); else sobel_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+        MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+    }
         break;
     case MI_FILTER_MEAN:
-        if (aligned) mean3_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
-        else mean3_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+    {
+#define MI_L(P) mean3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+        MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+    }
         break;
     case MI_FILTER_MEDIAN:
-        if (aligned) median3_kernel<true><<<grid, 256, 0, a.stream>>>(in, out, g);
-        else median3_kernel<false><<<grid, 256, 0, a.stream>>>(in, out, g);
+    {
+#define MI_L(P) median3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+        MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+    }
         break;
     case MI_FILTER_GAUSSIAN: {
         GaussW gw;
         gaussian_kernel_1d(a.ksize, a.sigma, gw.w);
         switch (a.ksize / 2) {
-        case 1: launch_gauss_sep<1>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 2: launch_gauss_sep<2>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 3: launch_gauss_sep<3>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 4: launch_gauss_sep<4>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 5: launch_gauss_sep<5>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 6: launch_gauss_sep<6>(aligned, grid, a.stream, in, out, g, gw); break;
-        case 7: launch_gauss_sep<7>(aligned, grid, a.stream, in, out, g, gw); break;
+        case 1: launch_gauss_sep<1>(pol, grid, a.stream, in, out, g, gw); break;
+        case 2: launch_gauss_sep<2>(pol, grid, a.stream, in, out, g, gw); break;
+        case 3: launch_gauss_sep<3>(pol, grid, a.stream, in, out, g, gw); break;
+        case 4: launch_gauss_sep<4>(pol, grid, a.stream, in, out, g, gw); break;
+        case 5: launch_gauss_sep<5>(pol, grid, a.stream, in, out, g, gw); break;
+        case 6: launch_gauss_sep<6>(pol, grid, a.stream, in, out, g, gw); break;
+        case 7: launch_gauss_sep<7>(pol, grid, a.stream, in, out, g, gw); break;
         default: return fail(MI_ERR_BAD_KERNEL_SIZE, "separable Gaussian supports kernel sizes 3..15");
         }
         break;

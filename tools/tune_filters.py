@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Times every filter kernel on a batch of 3840x2160 frames under different launch knobs
+(environment variables read by the library at each launch), interleaved in one process.
+Usage: python tools/tune_filters.py [batch] ; prints GB/s (8 B/pixel algorithmic) per config."""
+import itertools
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from cudaimageprocessing_amd import ops  # noqa: E402
+
+W, H = 3840, 2160
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+ROUNDS = 7
+
+frames = ops.synth(2, W, H, batch=B)
+out = torch.empty_like(frames)
+px = B * W * H
+
+FILTERS = {
+    "gray": lambda: ops.grayscale(frames, out),
+    "sobel": lambda: ops.sobel(frames, out),
+    "mean3": lambda: ops.mean_blur(frames, 3, out),
+    "median3": lambda: ops.median_blur(frames, 3, out),
+    "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),
+}
+EXTRA = {
+    "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
+    "gauss9": lambda: ops.gaussian_blur(frames, 9, 2.0, out),
+    "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
+    "median5": lambda: ops.median_blur(frames, 5, out),
+}
+
+
+def timed(fn, reps=3):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def sweep(filters, configs):
+    res = {(f, i): [] for f in filters for i in range(len(configs))}
+    for _ in range(ROUNDS):
+        for i, cfg in enumerate(configs):
+            for k, v in cfg.items():
+                os.environ[k] = str(v)
+            for f, fn in filters.items():
+                res[(f, i)].append(timed(fn))
+    print("config".ljust(44) + "".join(f"{f:>10s}" for f in filters))
+    for i, cfg in enumerate(configs):
+        label = " ".join(f"{k[3:]}={v}" for k, v in cfg.items())
+        cells = []
+        for f in filters:
+            ms = sorted(res[(f, i)])[ROUNDS // 2]
+            cells.append(f"{px * 8 / (ms * 1e-3) / 1e9:10.0f}")
+        print(label.ljust(44) + "".join(cells), flush=True)
+
+
+if __name__ == "__main__":
+    for fn in list(FILTERS.values()) + list(EXTRA.values()):
+        fn()
+    torch.cuda.synchronize()
+    mode = sys.argv[2] if len(sys.argv) > 2 else "main"
+    if mode == "main":
+        cfgs = [dict(MI_SOBEL_M4=x, MI_ROWS_PER_BAND=r)
+                for x, r in itertools.product((0, 1), (4, 6, 8, 16, 32))]
+        sweep(FILTERS, cfgs)
+    else:
+        cfgs = [dict(MI_NT=1, MI_XCD_REMAP=x, MI_ROWS_PER_BAND=r) for x in (0, 1) for r in (8, 16, 32, 64)]
+        sweep(EXTRA, cfgs)

@@ -2,17 +2,22 @@
 """bench.py -- BASELINE.json's headline metric: megapixels/s of the filter chain
 (gray -> Gaussian 5x5 -> median 3x3 -> Sobel) on 3840x2160 RGBA u8 frames, device-resident.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--unfused]
 
 A step is one pass of the chain over one batch of B synthetic frames per GPU (inputs already in
-HBM).  N>1 is launched by torch.distributed.run, one process per GPU; frames are independent, so
-ranks share nothing on the data path (batch sharding, weak scaling) and RCCL is used only for
-the barrier and the max-over-ranks time.  Rank 0 prints one JSON line.
+HBM): one launch of the fused chain kernel (mi_chain_gray_gauss5_median3_sobel_u8x4_dev, output
+bit-identical to the four single-filter kernels), or with --unfused the four kernels in turn.
+N>1 is launched by torch.distributed.run, one process per GPU; frames are independent, so ranks
+share nothing on the data path (batch sharding, weak scaling) and RCCL is used only for the
+barrier and the max-over-ranks time.  Rank 0 prints one JSON line.
 
 Extra objects in the line:
-  roofline      the slowest of the four kernels: algorithmic bytes (8 B/pixel: 4 read + 4
-                written) per launch / its average launch duration, measured with
-                HIP events on the launch stream inside the timed region, against 8 TB/s.
+  roofline      the kernel of the timed step (the slowest of the four with --unfused):
+                algorithmic bytes (8 B/pixel: 4 read + 4 written) per launch / its
+                average launch duration, measured with HIP events on the launch stream inside
+                the timed region, against 8 TB/s.
+  unfused       the same chain as four kernels (32 B/pixel through HBM), timed right after the
+                K steps with the same events: per-filter ms, MP/s, GB/s and roofline fraction.
   cpu_baseline  the CPU oracle (a scalar C port of the reference's arithmetic) timed on this
                 host on a bounded sample of the same workload, rank 0 at N=1 only.
 """
@@ -31,7 +36,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_PIXEL = 8.0           # algorithmic: 4 read + 4 written per u8x4 -> u8x4 filter
 STAGES = ["grayscale", "gaussian5", "median3", "sobel"]
 KERNELS = {"grayscale": "gray_kernel", "gaussian5": "gauss_sep_kernel<2>", "median3": "median3_kernel",
-           "sobel": "sobel_kernel"}
+           "sobel": "sobel_kernel", "fused": "chain_kernel"}
+# HBM bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+# FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) at the default workload
+# (batch 16): see profiles/.  None until measured for a kernel.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
 
 
 def cpu_baseline(frames=1, threads=1):
@@ -52,6 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="3840x2160 frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="time the four single-filter kernels as the step")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +90,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(events=None):
+    def unfused_step(events=None):
         stream = torch.cuda.current_stream()
         if events is not None:
             events[0].record(stream)
@@ -97,9 +107,20 @@ def main():
         if events is not None:
             events[4].record(stream)
 
+    def fused_step(events=None):
+        stream = torch.cuda.current_stream()
+        if events is not None:
+            events[0].record(stream)
+        ops.fused_chain(frames, 1.0, bufs[3])
+        if events is not None:
+            events[1].record(stream)
+
+    step = unfused_step if args.unfused else fused_step
+    n_ev = 5 if args.unfused else 2
+
     for _ in range(args.warmup):
         step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -112,14 +133,47 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel launch durations (ms) from the events recorded inside the timed region
-    per_stage = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
-                 for i in range(4)]
+    per_kernel = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
+                  for i in range(n_ev - 1)]
+
+    # the four-kernel chain, timed after the K steps (same buffers, same events)
+    if args.unfused:
+        per_stage, unfused_elapsed = per_kernel, elapsed
+    else:
+        unfused_step()
+        ev4 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            unfused_step(ev4[k])
+        torch.cuda.synchronize()
+        unfused_elapsed = time.perf_counter() - t1
+        per_stage = [sum(ev4[k][i].elapsed_time(ev4[k][i + 1]) for k in range(args.steps)) / args.steps
+                     for i in range(4)]
 
     if rank == 0:
         px_per_launch = B * W * H
         mp_total = world * B * W * H / 1e6 * args.steps
-        worst = max(range(4), key=lambda i: per_stage[i])
-        achieved = px_per_launch * BYTES_PER_PIXEL / (per_stage[worst] * 1e-3) / 1e9
+        alg_bytes = px_per_launch * BYTES_PER_PIXEL
+        traffic = {}
+        if os.path.exists(TRAFFIC_FILE) and B == 16:
+            traffic = json.load(open(TRAFFIC_FILE))
+
+        def gbs(ms):
+            return alg_bytes / (ms * 1e-3) / 1e9
+
+        per_filter = {STAGES[i]: {"kernel": KERNELS[STAGES[i]], "ms": per_stage[i],
+                                  "MP/s": px_per_launch / 1e6 / (per_stage[i] * 1e-3), "GB/s": gbs(per_stage[i]),
+                                  "roofline_frac": gbs(per_stage[i]) / HBM_PEAK_GBS,
+                                  "traffic": traffic.get(KERNELS[STAGES[i]])}
+                      for i in range(4)}
+        if args.unfused:
+            worst = max(range(4), key=lambda i: per_stage[i])
+            kname, kms = KERNELS[STAGES[worst]], per_stage[worst]
+            desc = "4 kernels per step (gray, gauss_sep<2>, median3, sobel)"
+        else:
+            kname, kms = KERNELS["fused"], per_kernel[0]
+            desc = "1 fused kernel per step (output bit-identical to the 4 single-filter kernels)"
         out = {
             "metric": "megapixels/sec, full filter chain (gray, Gaussian 5x5, median 3x3, Sobel)",
             "value": mp_total / elapsed,
@@ -134,18 +188,14 @@ def main():
             "dtype": "u8 (fp32 accumulate in grayscale/Gaussian)",
             "data": "synthetic",
             "config": {"workload": f"C2 chain gray->gauss5(sigma 1.0)->median3->sobel, {W}x{H} RGBA u8, "
-                                   f"batch {B} frames per GPU, device-resident, 4 kernels per step",
+                                   f"batch {B} frames per GPU, device-resident, {desc}",
                        "frames_per_gpu": B, "width": W, "height": H, "sharding": f"batch x{world}"},
-            "per_filter": {STAGES[i]: {"ms": per_stage[i],
-                                       "MP/s": px_per_launch / 1e6 / (per_stage[i] * 1e-3),
-                                       "GB/s": px_per_launch * BYTES_PER_PIXEL / (per_stage[i] * 1e-3) / 1e9,
-                                       "roofline_frac": px_per_launch * BYTES_PER_PIXEL / (per_stage[i] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                           for i in range(4)},
-            "roofline": {"kernel": KERNELS[STAGES[worst]], "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "algorithmic_bytes_per_launch": px_per_launch * BYTES_PER_PIXEL,
-                         "avg_launch_ms": per_stage[worst]},
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": gbs(kms),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(kms) / HBM_PEAK_GBS,
+                         "traffic": traffic.get(kname),
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kms},
+            "unfused": {"value": B * W * H / 1e6 * args.steps / unfused_elapsed, "unit": "MP/s (rank 0)",
+                        "ms_per_step": unfused_elapsed / args.steps * 1e3, "per_filter": per_filter},
         }
         if world == 1 and not args.no_cpu_baseline:
             v, dt = cpu_baseline(frames=8, threads=1)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "mi_gaussian_u8x4_dev": [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "mi_meanblur_u8x4_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mi_medianblur_u8x4_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mi_chain_gray_gauss5_median3_sobel_u8x4_dev": [_vp, _vp, _i, _i, _i, _f, _vp],
     "mi_filter_strip_u8x4_dev": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "mi_filter_halo_rows": [_i, _i],
     "mi_synth_u8x4_dev": [_vp, _u64, _u64, _u64, _vp],

@@ -241,6 +241,17 @@ int mi_medianblur_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batc
     return run_frames(MI_FILTER_MEDIAN, d_in, d_out, w, h, batch, kernel_size, 0.f, stream);
 }
 
+int mi_chain_gray_gauss5_median3_sobel_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, float sigma, void* stream)
+{
+    int rc = check_image(d_in, d_out, w, h, batch);
+    if (rc) return rc;
+    rc = check_filter(MI_FILTER_GAUSSIAN, w, h, 5, sigma);
+    if (rc) return rc;
+    const size_t bytes = (size_t)w * h * 4 * batch;
+    if (overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "device-tier in/out buffers overlap");
+    return launch_chain(d_in, d_out, w, h, batch, sigma, (hipStream_t)stream);
+}
+
 int mi_filter_halo_rows(int filter, int param_i) { return filter_halo_rows(filter, param_i); }
 
 int mi_filter_strip_u8x4_dev(int filter, const void* d_in, void* d_out, int w, int h_total,

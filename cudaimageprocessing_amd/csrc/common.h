@@ -4,8 +4,9 @@
 // strip of 64*4 pixels and marches down a band of rows.  Every lane holds 4 adjacent pixels
 // (one 16-byte load per row), keeps the rows of the stencil window in registers, and gets its
 // left/right neighbours' pixels from the adjacent lanes with DPP wave shifts -- no LDS, no
-// barriers.  The outermost M lanes on each side of a wave only feed their neighbours (their
-// own outputs are produced by the adjacent strip), so strips overlap by 2*M lanes.
+// barriers.  All 64 lanes produce output (a wave-row is one aligned 1-KiB store); the pixels
+// beyond the strip's edges come from a second, two-lane "halo" load per row whose value enters
+// the DPP shift as the edge lanes' own operand.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,10 +38,10 @@ struct Geo {
     i64 out_frame_stride;
 };
 
-// lane i <- lane i-1 (lane 0 <- 0)
-MI_DEV u32 from_left(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, false); }
-// lane i <- lane i+1 (lane 63 <- 0)
-MI_DEV u32 from_right(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, false); }
+// lane i <- lane i-1; lane 0, which has no left neighbour in the wave, keeps its own `edge`
+MI_DEV u32 from_left(u32 v, u32 edge = 0u) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
+// lane i <- lane i+1; lane 63 keeps its own `edge`
+MI_DEV u32 from_right(u32 v, u32 edge = 0u) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
 
 MI_DEV u32 pk_min(u32 a, u32 b)
 {
@@ -116,7 +117,7 @@ MI_DEV WaveJob wave_job(const Geo& g)
     const int waves_per_block = blockDim.x >> 6;
     const u32 nblk = gridDim.x, b = blockIdx.x;
     const u32 q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    const u32 logical = g.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
+    const u32 logical = (g.xcd_remap & 1) ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
     int wid = (int)logical * waves_per_block + (int)(threadIdx.x >> 6);
     wid = __builtin_amdgcn_readfirstlane(wid);
     WaveJob j;
@@ -170,15 +171,25 @@ struct RowIO<0> {
     const u32* in;
     u32* out;
     const Geo* g;
-    int cx;
+    int cx, lane;
     bool productive;
-    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g_, const WaveJob& j, const March&, int cx0, int margin)
+    // margin: lanes at each edge of the wave that only feed their neighbours (overlapping strips)
+    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g_, const WaveJob& j, const March&, int cx0, int margin = 0)
         : in(in_ + (i64)j.frame * g_.in_frame_stride), out(out_ + (i64)j.frame * g_.out_frame_stride), g(&g_)
     {
+        lane = j.lane;
         cx = cx0 + 4 * j.lane;
-        productive = j.lane >= margin && j.lane < 64 - margin && cx < g_.W;
+        productive = cx < g_.W && j.lane >= margin && j.lane < 64 - margin;
     }
     MI_DEV u32x4 load(int row) const { return load_px4<0>(in, *g, (i64)row * g->W + cx); }
+    // the 4 pixels `hop` groups left of the strip (lane 0) / right of it (lane 63); 0 elsewhere
+    MI_DEV u32x4 load_halo(int row, int hop) const
+    {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (lane == 0) v = load_px4<0>(in, *g, (i64)row * g->W + cx - 4 * hop);
+        else if (lane == 63) v = load_px4<0>(in, *g, (i64)row * g->W + cx + 4 * hop);
+        return v;
+    }
     MI_DEV void store(int y, u32x4 v) const { if (productive) store_px4<0>(out, *g, y, cx, v); }
 };
 
@@ -186,33 +197,63 @@ template <>
 struct RowIO<1> {
     __amdgpu_buffer_rsrc_t rin, rout;
     int in_off;    // byte offset of this lane's 4 pixels in row `row0`, relative to rin's base
+    int halo_off;  // the same for the halo group one hop away (out of range for lanes 1..62)
+    int halo_dir;  // -16 for lane 0, +16 for lane 63: byte step per extra hop
     u32 out_off;   // same for rout; 0x80000000 (out of range) for lanes that must not store
     int row0, ylo, pitch;
-    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g, const WaveJob& j, const March& m, int cx0, int margin)
+    MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g, const WaveJob& j, const March& m, int cx0, int margin = 0)
     {
         const u32* in = in_ + (i64)j.frame * g.in_frame_stride;
         u32* out = out_ + (i64)j.frame * g.out_frame_stride;
         ylo = m.dir > 0 ? m.ys : m.ys - (m.n - 1);
         row0 = ylo - 16;                       // any row at or above the first one loaded
         pitch = g.W * 4;
-        const i64 fmin = (i64)row0 * g.W + cx0;          // lowest flat index this wave can touch
+        const i64 fmin = (i64)row0 * g.W + cx0 - 8;      // lowest flat index this wave can touch
         const i64 base = fmin > g.in_lo ? fmin : g.in_lo;
         i64 bytes = (g.in_hi - base) * 4;
         bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFF00LL ? 0x7FFFFF00LL : bytes);
         rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
-        in_off = (int)((fmin - base) * 4) + 16 * j.lane;
+        in_off = (int)((fmin + 8 - base) * 4) + 16 * j.lane;
+        halo_dir = j.lane == 0 ? -16 : 16;
+        halo_off = (j.lane == 0 || j.lane == 63) ? in_off + halo_dir : (int)0x80000000;
         const i64 obase = (i64)ylo * g.W;
         rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (obase - g.out_origin)), 0, m.n * pitch, 0x00020000);
         const int cx = cx0 + 4 * j.lane;
-        const bool productive = j.lane >= margin && j.lane < 64 - margin && cx < g.W;
-        out_off = productive ? (u32)(cx * 4) : 0x80000000u;
+        out_off = (cx < g.W && j.lane >= margin && j.lane < 64 - margin) ? (u32)(cx * 4) : 0x80000000u;
     }
     MI_DEV u32x4 load(int row) const
     {
         return __builtin_amdgcn_raw_buffer_load_b128(rin, (row - row0) * pitch + in_off, 0, 0);
     }
+    MI_DEV u32x4 load_halo(int row, int hop) const
+    {
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, (row - row0) * pitch + halo_off + (hop - 1) * halo_dir, 0, 0);
+    }
     MI_DEV void store(int y, u32x4 v) const
     {   // aux 2 = nt: streaming store, the output is not read again by this kernel
         __builtin_amdgcn_raw_buffer_store_b128(v, rout, (u32)((y - ylo) * pitch) + out_off, 0, 2);
+    }
+};
+
+// The rows a wave has asked for but not yet used: PF rows (main vector + one-hop halo) in flight.
+// One row in flight per wave is not enough to cover the HBM latency under load (8192 resident
+// waves x 1 KiB = 8 MB in flight ~ 2.6 TB/s x 3 us); PF rows multiply that.
+template <int POL, int PF>
+struct RowQueue {
+    u32x4 p[PF], h[PF];
+    // queue input steps first .. first+PF-1
+    MI_DEV void fill(const RowIO<POL>& io, const March& m, int first)
+    {
+#pragma unroll
+        for (int k = 0; k < PF; k++) { p[k] = io.load(m.row(first + k)); h[k] = io.load_halo(m.row(first + k), 1); }
+    }
+    // take the oldest row (input step `step`) and queue input step `step + PF`
+    MI_DEV void pop(const RowIO<POL>& io, const March& m, int step, u32x4& pv, u32x4& hv)
+    {
+        pv = p[0]; hv = h[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PF; k++) { p[k] = p[k + 1]; h[k] = h[k + 1]; }
+        p[PF - 1] = io.load(m.row(step + PF));
+        h[PF - 1] = io.load_halo(m.row(step + PF), 1);
     }
 };

@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256) void fft_small_kernel(const c2* __restrict__ i
 }
 
 // ---------------------------------------------------------------- host side
+static int env_group_mib()
+{
+    const char* v = getenv("MI_FFT_GROUP_MIB");
+    return (v && *v) ? atoi(v) : 160;
+}
+
 static int ensure_twiddles(hipStream_t s)
 {
     static std::mutex mu;
@@ -315,22 +321,36 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
 {
     int rc = ensure_twiddles(s);
     if (rc) return rc;
-    FftGeo g;
-    g.inverse = dir > 0;
-    g.plane_stride = (i64)rows * cols;
-    // rows: lines of `cols` contiguous points
-    g.lines_per_plane = rows;
-    g.total_lines = (i64)rows * batch;
-    g.line_stride = cols;
-    g.elem_stride = 1;
-    rc = launch_pass<false>(cols, (const c2*)in, (c2*)out, g, s);
-    if (rc) return rc;
-    // columns, in place on the row-pass output
-    g.lines_per_plane = cols;
-    g.total_lines = (i64)cols * batch;
-    g.line_stride = 1;
-    g.elem_stride = cols;
-    return launch_pass<true>(rows, (const c2*)out, (c2*)out, g, s);
+    // Planes are transformed in groups that fit the 256 MiB Infinity Cache (row pass then column
+    // pass on the same group), so the column pass finds the row pass's output on die instead of
+    // re-reading it from HBM.  MI_FFT_GROUP_MIB=0 restores one row pass and one column pass over
+    // the whole batch.
+    const i64 plane_bytes = (i64)rows * cols * 8;
+    const i64 budget = (i64)env_group_mib() << 20;
+    int group = budget <= 0 ? batch : (int)std::max<i64>(1, std::min<i64>(batch, budget / plane_bytes));
+    for (int b0 = 0; b0 < batch; b0 += group) {
+        const int nb = std::min(group, batch - b0);
+        const c2* pin = (const c2*)in + (i64)b0 * rows * cols;
+        c2* pout = (c2*)out + (i64)b0 * rows * cols;
+        FftGeo g;
+        g.inverse = dir > 0;
+        g.plane_stride = (i64)rows * cols;
+        // rows: lines of `cols` contiguous points
+        g.lines_per_plane = rows;
+        g.total_lines = (i64)rows * nb;
+        g.line_stride = cols;
+        g.elem_stride = 1;
+        rc = launch_pass<false>(cols, pin, pout, g, s);
+        if (rc) return rc;
+        // columns, in place on the row-pass output
+        g.lines_per_plane = cols;
+        g.total_lines = (i64)cols * nb;
+        g.line_stride = 1;
+        g.elem_stride = cols;
+        rc = launch_pass<true>(rows, pout, pout, g, s);
+        if (rc) return rc;
+    }
+    return MI_OK;
 }
 
 }  // namespace mi

@@ -83,34 +83,45 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
     r23 = __builtin_amdgcn_perm(p.w, p.z, 0x0c040c00u);
 }
 
-template <int POL, int M = 1>
+// Common prologue of the wave-march kernels: this wave's strip, band and I/O.
+#define MI_MARCH_PROLOGUE()                                                                      \
+    const WaveJob j = wave_job(g);                                                               \
+    if (!j.valid) return;                                                                        \
+    const int cx = j.strip * 256 + 4 * j.lane;   /* first of this lane's 4 columns */           \
+    const March mch = make_march(g, j);                                                          \
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * 256);                                      \
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)}
+
+template <int POL, int PF>
 __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
-    const WaveJob j = wave_job(g);
-    if (!j.valid) return;
-    constexpr int OUTW = 4 * (64 - 2 * M);
-    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const March mch = make_march(g, j);
-    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
-    const u32 xm0 = xmask(cx, g.W), xm1 = xmask(cx + 1, g.W), xm2 = xmask(cx + 2, g.W),
-              xm3 = xmask(cx + 3, g.W);
+    MI_MARCH_PROLOGUE();
+    // Red bytes of the halo pixels as one packed pair: low half = first pixel right of the strip
+    // (meaningful in lane 63), high half = last pixel left of it (meaningful in lane 0).
+    auto halo_red = [](u32x4 h) { return __builtin_amdgcn_perm(h.w, h.x, 0x0c040c00u); };
 
-    u32 t01, t23, m01, m23, b01, b23;
+    u32 t01, t23, m01, m23, b01, b23, th, mh, bh;
     // t = oldest row of the window, b = newest.  Marching up swaps their roles, which only flips
     // the sign of Gy; Gx^2 + Gy^2 does not change.
     red_pairs(io.load(mch.row(-1)), t01, t23);
+    th = halo_red(io.load_halo(mch.row(-1), 1));
     red_pairs(io.load(mch.row(0)), m01, m23);
-    u32x4 nxt = io.load(mch.row(1));
+    mh = halo_red(io.load_halo(mch.row(0), 1));
+    RowQueue<POL, PF> q;
+    q.fill(io, mch, 1);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
+        u32x4 nxt, nxh;
+        q.pop(io, mch, i + 1, nxt, nxh);
         red_pairs(nxt, b01, b23);
-        nxt = io.load(mch.row(i + 2));  // prefetch the next row
+        bh = halo_red(nxh);
         const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
         const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
-        const u32 D01 = pk_sub(b01, t01), D23 = pk_sub(b23, t23);
-        const u32 VL = from_left(V23), VR = from_right(V01);
-        const u32 DL = from_left(D23), DR = from_right(D01);
+        const u32 VH = pk_add(pk_add(th, bh), pk_add(mh, mh));
+        const u32 D01 = pk_sub(b01, t01), D23 = pk_sub(b23, t23), DH = pk_sub(bh, th);
+        const u32 VL = from_left(V23, VH), VR = from_right(V01, VH);
+        const u32 DL = from_left(D23, DH), DR = from_right(D01, DH);
         const u32 Va = __builtin_amdgcn_alignbit(V01, VL, 16);  // (V-1, V0)
         const u32 Vb = __builtin_amdgcn_alignbit(V23, V01, 16); // (V1, V2)
         const u32 Vc = __builtin_amdgcn_alignbit(VR, V23, 16);  // (V3, V4)
@@ -121,18 +132,20 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
         const u32 Gy01 = pk_add(pk_add(Da, Db), pk_add(D01, D01));
         const u32 Gy23 = pk_add(pk_add(Db, Dc), pk_add(D23, D23));
         // (Gx_j, Gy_j) as one s16x2, s_j = Gx_j^2 + Gy_j^2 with one dot2
-        const u32 P0 = __builtin_amdgcn_perm(Gy01, Gx01, 0x05040100u);
-        const u32 P1 = __builtin_amdgcn_perm(Gy01, Gx01, 0x07060302u);
-        const u32 P2 = __builtin_amdgcn_perm(Gy23, Gx23, 0x05040100u);
-        const u32 P3 = __builtin_amdgcn_perm(Gy23, Gx23, 0x07060302u);
+        const u32 P[4] = {__builtin_amdgcn_perm(Gy01, Gx01, 0x05040100u), __builtin_amdgcn_perm(Gy01, Gx01, 0x07060302u),
+                          __builtin_amdgcn_perm(Gy23, Gx23, 0x05040100u), __builtin_amdgcn_perm(Gy23, Gx23, 0x07060302u)};
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
-        u32x4 o;
-        o.x = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P0), __builtin_bit_cast(s16x2, P0), 0, false)) * 0x010101u | 0xFF000000u) & xm0 & rowm;
-        o.y = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P1), __builtin_bit_cast(s16x2, P1), 0, false)) * 0x010101u | 0xFF000000u) & xm1 & rowm;
-        o.z = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P2), __builtin_bit_cast(s16x2, P2), 0, false)) * 0x010101u | 0xFF000000u) & xm2 & rowm;
-        o.w = (sobel_mag(__builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, P3), __builtin_bit_cast(s16x2, P3), 0, false)) * 0x010101u | 0xFF000000u) & xm3 & rowm;
-        io.store(y, o);
-        t01 = m01; t23 = m23; m01 = b01; m23 = b23;
+        u32 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
+            o[k] = (sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)) * 0x010101u | 0xFF000000u) & xm[k] & rowm;
+        }
+        if (g.xcd_remap & 2) {   // EXPERIMENT: memory structure only
+            io.store(y, u32x4{m01 ^ t01 ^ b01, m23 ^ t23 ^ b23, th ^ mh ^ bh, m01});
+        } else
+        io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+        t01 = m01; t23 = m23; th = mh; m01 = b01; m23 = b23; mh = bh;
     }
 }
 
@@ -164,23 +177,17 @@ template <int POL>
 __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
-    const WaveJob j = wave_job(g);
-    if (!j.valid) return;
-    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
-    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const March mch = make_march(g, j);
-    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
-    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    MI_MARCH_PROLOGUE();
 
     // horizontal 3-sums of one row, per pixel, as (lo, hi) packed pairs
-    auto hsum = [&](u32x4 p, u32 (&hl)[4], u32 (&hh)[4]) {
+    auto hsum = [&](u32x4 p, u32x4 h, u32 (&hl)[4], u32 (&hh)[4]) {
         u32 lo[6], hi[6];
-        unpack_px(from_left(p.w), lo[0], hi[0]);
+        unpack_px(from_left(p.w, h.w), lo[0], hi[0]);
         unpack_px(p.x, lo[1], hi[1]);
         unpack_px(p.y, lo[2], hi[2]);
         unpack_px(p.z, lo[3], hi[3]);
         unpack_px(p.w, lo[4], hi[4]);
-        unpack_px(from_right(p.x), lo[5], hi[5]);
+        unpack_px(from_right(p.x, h.x), lo[5], hi[5]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             hl[k] = pk_add(pk_add(lo[k], lo[k + 1]), lo[k + 2]);
@@ -189,13 +196,14 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    hsum(io.load(mch.row(-1)), tl, th);
-    hsum(io.load(mch.row(0)), ml, mh);
-    u32x4 nxt = io.load(mch.row(1));
+    hsum(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), tl, th);
+    hsum(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), ml, mh);
+    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
-        hsum(nxt, bl, bh);
+        hsum(nxt, nxh, bl, bh);
         nxt = io.load(mch.row(i + 2));
+        nxh = io.load_halo(mch.row(i + 2), 1);
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
         u32 o[4];
 #pragma unroll
@@ -230,42 +238,42 @@ template <int POL>
 __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in,
                                                       u32* __restrict__ out, const Geo g)
 {
-    const WaveJob j = wave_job(g);
-    if (!j.valid) return;
-    constexpr int M = 1, OUTW = 4 * (64 - 2 * M);
-    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const March mch = make_march(g, j);
-    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
-    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    MI_MARCH_PROLOGUE();
+    const bool first_lane = j.lane == 0;
 
-    auto unpack4 = [&](u32x4 p, u32 (&l)[4], u32 (&h)[4]) {
-        unpack_px(p.x, l[0], h[0]); unpack_px(p.y, l[1], h[1]);
-        unpack_px(p.z, l[2], h[2]); unpack_px(p.w, l[3], h[3]);
+    // columns 0..3 = this lane's pixels, column 4 = the halo pixel (left of the strip in lane 0,
+    // right of it in lane 63)
+    auto unpack5 = [&](u32x4 p, u32x4 h, u32 (&l)[5], u32 (&hh)[5]) {
+        unpack_px(p.x, l[0], hh[0]); unpack_px(p.y, l[1], hh[1]);
+        unpack_px(p.z, l[2], hh[2]); unpack_px(p.w, l[3], hh[3]);
+        unpack_px(first_lane ? h.w : h.x, l[4], hh[4]);
     };
 
-    u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    unpack4(io.load(mch.row(-1)), tl, th);
-    unpack4(io.load(mch.row(0)), ml, mh);
-    u32x4 nxt = io.load(mch.row(1));
+    u32 tl[5], th[5], ml[5], mh[5], bl[5], bh[5];
+    unpack5(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), tl, th);
+    unpack5(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), ml, mh);
+    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
-        unpack4(nxt, bl, bh);
+        unpack5(nxt, nxh, bl, bh);
         nxt = io.load(mch.row(i + 2));
+        nxh = io.load_halo(mch.row(i + 2), 1);
         // sorted columns: index 0 = left neighbour's column 3, 1..4 = own, 5 = right's column 0
         u32 cl[6][2], cm[6][2], ch[6][2];   // [column][0=lo pair (R,B), 1=hi pair (G,A)]
+        u32 hl[2], hm[2], hh[2];            // the sorted halo column
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             u32 a = tl[k], b = ml[k], c = bl[k];
             sort2(a, b); sort2(b, c); sort2(a, b);
-            cl[k + 1][0] = a; cm[k + 1][0] = b; ch[k + 1][0] = c;
+            if (k < 4) { cl[k + 1][0] = a; cm[k + 1][0] = b; ch[k + 1][0] = c; } else { hl[0] = a; hm[0] = b; hh[0] = c; }
             a = th[k]; b = mh[k]; c = bh[k];
             sort2(a, b); sort2(b, c); sort2(a, b);
-            cl[k + 1][1] = a; cm[k + 1][1] = b; ch[k + 1][1] = c;
+            if (k < 4) { cl[k + 1][1] = a; cm[k + 1][1] = b; ch[k + 1][1] = c; } else { hl[1] = a; hm[1] = b; hh[1] = c; }
         }
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            cl[0][s] = from_left(cl[4][s]); cm[0][s] = from_left(cm[4][s]); ch[0][s] = from_left(ch[4][s]);
-            cl[5][s] = from_right(cl[1][s]); cm[5][s] = from_right(cm[1][s]); ch[5][s] = from_right(ch[1][s]);
+            cl[0][s] = from_left(cl[4][s], hl[s]); cm[0][s] = from_left(cm[4][s], hm[s]); ch[0][s] = from_left(ch[4][s], hh[s]);
+            cl[5][s] = from_right(cl[1][s], hl[s]); cm[5][s] = from_right(cm[1][s], hm[s]); ch[5][s] = from_right(ch[1][s], hh[s]);
         }
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
         u32 o[4];
@@ -280,8 +288,9 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
                 r[s] = med3(a, b, c);
             }
             o[k] = (r[0] | (r[1] << 8) | 0xFF000000u) & xm[k] & rowm;
-            tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k];
         }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k]; }
         io.store(y, u32x4{o[0], o[1], o[2], o[3]});
     }
 }
@@ -301,28 +310,34 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
                                                         const GaussW gw)
 {
     constexpr int K = 2 * R + 1;
-    constexpr int M = (R + 3) / 4;
-    constexpr int OUTW = 4 * (64 - 2 * M);
-    const WaveJob j = wave_job(g);
-    if (!j.valid) return;
-    const int cx = j.strip * OUTW - 4 * M + 4 * j.lane;
-    const March mch = make_march(g, j);
-    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * M, M);
-    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    constexpr int HOPS = (R + 3) / 4;   // 4-pixel groups needed beyond each edge of the strip
+    MI_MARCH_PROLOGUE();
+
+    struct RowIn { u32x4 p, h1, h2; };
+    auto load_row = [&](int row) {
+        RowIn r;
+        r.p = io.load(row);
+        r.h1 = io.load_halo(row, 1);
+        if (HOPS > 1) r.h2 = io.load_halo(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
+        return r;
+    };
 
     // Row pass: h[3*k+c] = sum_t w[t] * channel c of column (k - R + t), k = 0..3.
-    auto hrow = [&](u32x4 p, float (&h)[12]) {
+    auto hrow = [&](const RowIn& r, float (&h)[12]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
-        col[8] = p.x; col[9] = p.y; col[10] = p.z; col[11] = p.w;
+        const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+        const u32 e1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        const u32 e2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            col[4 + k] = from_left(col[8 + k]);
-            col[12 + k] = from_right(col[8 + k]);
+            col[8 + k] = p[k];
+            col[4 + k] = from_left(p[k], e1[k]);
+            col[12 + k] = from_right(p[k], e1[k]);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            col[k] = from_left(col[4 + k]);
-            col[16 + k] = from_right(col[12 + k]);
+            col[k] = from_left(col[4 + k], e2[k]);
+            col[16 + k] = from_right(col[12 + k], e2[k]);
         }
         float f[4 + 2 * R][3];
 #pragma unroll
@@ -348,8 +363,8 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
     // marching direction does not matter to the column pass)
 #pragma unroll
     for (int i = 0; i < K - 1; i++)
-        hrow(io.load(mch.row(i - R)), win[i]);
-    u32x4 nxt = io.load(mch.row(R));
+        hrow(load_row(mch.row(i - R)), win[i]);
+    RowIn nxt = load_row(mch.row(R));
 
     for (int base = 0; base < mch.n; base += K) {
 #pragma unroll
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
             const int y = mch.row(i);
             // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
             hrow(nxt, win[(K - 1 + s) % K]);
-            nxt = io.load(mch.row(i + R + 1));
+            nxt = load_row(mch.row(i + R + 1));
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -379,6 +394,130 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
                 o[k] = ((u32)acc[0] | ((u32)acc[1] << 8) | ((u32)acc[2] << 16) | 0xFF000000u) & xm[k] & rowm;
             }
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+            }
+        }
+    }
+}
+
+// ============================================================================ fused chain
+// gray -> Gaussian 5x5 -> median 3x3 -> Sobel (BASELINE.json config 2) in one pass: 8 bytes of
+// HBM traffic per pixel instead of 32.  After the grayscale stage the three colour channels are
+// equal, and every later stage treats them alike, so the pipeline carries ONE value per pixel;
+// the arithmetic of each stage is the single-filter kernel's own, operation for operation, and
+// each stage's output is zeroed outside the reference's write set before the next stage reads
+// it, so the result is bit-identical to running the four kernels one after the other.
+// The stages have a combined reach of 4 pixels: strips overlap by one lane on each side
+// (62 productive lanes) and a band reads 4 extra rows above and below.
+template <int POL>
+__global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
+                                                    u32* __restrict__ out, const Geo g,
+                                                    const GaussW gw)
+{
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    constexpr int OUTW = 4 * 62;
+    const int cx = j.strip * OUTW - 4 + 4 * j.lane;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4, 1);
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    const u32 pm01 = (xm[0] & 0xFFFFu) | (xm[1] & 0xFFFF0000u), pm23 = (xm[2] & 0xFFFFu) | (xm[3] & 0xFFFF0000u);
+    auto rowmask = [&](int y) { return (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u; };
+
+    // stage 1+2a: grayscale of 4 pixels (as floats holding integers), then the Gaussian row pass
+    auto gray_hrow = [&](u32x4 p, float (&h)[4]) {
+        float f[8];
+        const u32 px[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float r = (float)(px[k] & 0xffu), gg = (float)((px[k] >> 8) & 0xffu), b = (float)((px[k] >> 16) & 0xffu);
+            const float t = 0.587f * gg;
+            const float u = __builtin_fmaf(0.299f, r, t);
+            f[2 + k] = __builtin_floorf(__builtin_fmaf(0.114f, b, u));   // == (float)(uchar)v, v >= 0
+        }
+        f[0] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[4])));
+        f[1] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[5])));
+        f[6] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[2])));
+        f[7] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[3])));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float s = gw.w[0] * f[k];
+#pragma unroll
+            for (int t = 1; t < 5; t++) s = __builtin_fmaf(gw.w[t], f[k + t], s);
+            h[k] = s;
+        }
+    };
+
+    float win[5][4];
+    u32 gt01 = 0, gt23 = 0, gm01 = 0, gm23 = 0;         // Gaussian output rows (median window), packed u16 pairs
+    u32 mt01 = 0, mt23 = 0, mm01 = 0, mm23 = 0;         // median output rows (Sobel window)
+#pragma unroll
+    for (int i = 0; i < 4; i++) gray_hrow(io.load(mch.row(i - 4)), win[i]);
+    u32x4 nxt = io.load(mch.row(0));
+
+    const int steps = mch.n + 4;   // input steps 0 .. n+3; step i completes output row i-4
+    for (int base = 0; base < steps; base += 5) {
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const int i = base + s;
+            if (i < steps) {
+            gray_hrow(nxt, win[(4 + s) % 5]);
+            nxt = io.load(mch.row(i + 1));
+            // ---- Gaussian column pass: row(i-2), zero outside the write set
+            const u32 grow = rowmask(mch.row(i - 2));
+            u32 b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float a = gw.w[2] * win[(s + 2) % 5][k];
+                a = __builtin_fmaf(gw.w[0], win[s % 5][k] + win[(s + 4) % 5][k], a);
+                a = __builtin_fmaf(gw.w[1], win[(s + 1) % 5][k] + win[(s + 3) % 5][k], a);
+                b[k] = (u32)a;
+            }
+            const u32 gb01 = (b[0] | (b[1] << 16)) & pm01 & grow, gb23 = (b[2] | (b[3] << 16)) & pm23 & grow;
+            // ---- median 3x3: row(i-3) from Gaussian rows (gt, gm, gb)
+            u32 l01 = gt01, m01 = gm01, h01 = gb01, l23 = gt23, m23 = gm23, h23 = gb23;
+            sort2(l01, m01); sort2(m01, h01); sort2(l01, m01);
+            sort2(l23, m23); sort2(m23, h23); sort2(l23, m23);
+            u32 med01, med23;
+            {
+                const u32 lL = from_left(l23), mL = from_left(m23), hL = from_left(h23);
+                const u32 lR = from_right(l01), mR = from_right(m01), hR = from_right(h01);
+                const u32 la = __builtin_amdgcn_alignbit(l01, lL, 16), lb = __builtin_amdgcn_alignbit(l23, l01, 16), lc = __builtin_amdgcn_alignbit(lR, l23, 16);
+                const u32 ma = __builtin_amdgcn_alignbit(m01, mL, 16), mb = __builtin_amdgcn_alignbit(m23, m01, 16), mc = __builtin_amdgcn_alignbit(mR, m23, 16);
+                const u32 ha = __builtin_amdgcn_alignbit(h01, hL, 16), hb = __builtin_amdgcn_alignbit(h23, h01, 16), hc = __builtin_amdgcn_alignbit(hR, h23, 16);
+                const u32 mrow = rowmask(mch.row(i - 3));
+                med01 = med3(pk_max(pk_max(la, l01), lb), med3(ma, m01, mb), pk_min(pk_min(ha, h01), hb)) & pm01 & mrow;
+                med23 = med3(pk_max(pk_max(lb, l23), lc), med3(mb, m23, mc), pk_min(pk_min(hb, h23), hc)) & pm23 & mrow;
+            }
+            gt01 = gm01; gt23 = gm23; gm01 = gb01; gm23 = gb23;
+            // ---- Sobel: row(i-4) from median rows (mt, mm, med)
+            {
+                const u32 V01 = pk_add(pk_add(mt01, med01), pk_add(mm01, mm01));
+                const u32 V23 = pk_add(pk_add(mt23, med23), pk_add(mm23, mm23));
+                const u32 D01 = pk_sub(med01, mt01), D23 = pk_sub(med23, mt23);
+                const u32 VL = from_left(V23), VR = from_right(V01);
+                const u32 DL = from_left(D23), DR = from_right(D01);
+                const u32 Va = __builtin_amdgcn_alignbit(V01, VL, 16);
+                const u32 Vb = __builtin_amdgcn_alignbit(V23, V01, 16);
+                const u32 Vc = __builtin_amdgcn_alignbit(VR, V23, 16);
+                const u32 Da = __builtin_amdgcn_alignbit(D01, DL, 16);
+                const u32 Db = __builtin_amdgcn_alignbit(D23, D01, 16);
+                const u32 Dc = __builtin_amdgcn_alignbit(DR, D23, 16);
+                const u32 Gx01 = pk_sub(Vb, Va), Gx23 = pk_sub(Vc, Vb);
+                const u32 Gy01 = pk_add(pk_add(Da, Db), pk_add(D01, D01));
+                const u32 Gy23 = pk_add(pk_add(Db, Dc), pk_add(D23, D23));
+                const u32 P[4] = {__builtin_amdgcn_perm(Gy01, Gx01, 0x05040100u), __builtin_amdgcn_perm(Gy01, Gx01, 0x07060302u),
+                                  __builtin_amdgcn_perm(Gy23, Gx23, 0x05040100u), __builtin_amdgcn_perm(Gy23, Gx23, 0x07060302u)};
+                const int y = mch.row(i - 4);
+                const u32 srow = rowmask(y);
+                u32 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
+                    o[k] = (sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)) * 0x010101u | 0xFF000000u) & xm[k] & srow;
+                }
+                if (i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+            }
+            mt01 = mm01; mt23 = mm23; mm01 = med01; mm23 = med23;
             }
         }
     }
@@ -574,6 +713,40 @@ static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u3
 #undef MI_L
 }
 
+int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float sigma, hipStream_t stream)
+{
+    const u32* in = (const u32*)d_in;
+    u32* out = (u32*)d_out;
+    const bool aligned = (W % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    Geo g;
+    g.W = W; g.H = H; g.batch = batch;
+    g.y_begin = 0; g.y_end = H;
+    g.N = (i64)W * H;
+    g.in_origin = 0; g.in_lo = 0; g.in_hi = g.N; g.out_origin = 0;
+    g.in_frame_stride = g.N; g.out_frame_stride = g.N;
+    g.strips = (W + 247) / 248;
+    // VALU-bound, not HBM-bound: tall bands amortise the 8 extra rows a band runs through the
+    // early stages; shrink them only to fill the machine
+    int rpb = env_int("MI_CHAIN_ROWS_PER_BAND", 0);
+    if (rpb <= 0) {
+        rpb = 64;
+        while (rpb > 8 && (i64)batch * g.strips * ((H + rpb - 1) / rpb) < 8192) rpb >>= 1;
+    }
+    rpb = std::max(1, std::min(rpb, (int)((1LL << 28) / W)));
+    g.rows_per_band = rpb;
+    g.bands = (H + rpb - 1) / rpb;
+    const i64 total = (i64)batch * g.bands * g.strips;
+    if (total > 0x7fffffff / 64) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
+    g.total_waves = (int)total;
+    g.xcd_remap = 1;
+    GaussW gw;
+    gaussian_kernel_1d(5, sigma, gw.w);
+    const int grid = (int)((total + 3) / 4);
+    if (aligned) chain_kernel<1><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    else chain_kernel<0><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    return hip_status(hipGetLastError(), "chain kernel launch");
+}
+
 int launch_filter(const FilterArgs& a)
 {
     const int W = a.w, H = a.h_total;
@@ -644,11 +817,7 @@ int launch_filter(const FilterArgs& a)
     }
 
     // wave-march kernels
-    int margin = 1;
-    if (a.filter == MI_FILTER_GAUSSIAN) margin = (a.ksize / 2 + 3) / 4;
-    if (a.filter == MI_FILTER_SOBEL && env_int("MI_SOBEL_M4", 0)) margin = 4;
-    const int outw = 4 * (64 - 2 * margin);
-    g.strips = (W + outw - 1) / outw;
+    g.strips = (W + 255) / 256;   // a wave covers 64 lanes x 4 pixels
     // Rows per band.  Short bands keep the waves that run together on nearby rows, so the
     // access stream stays close to a front-to-back sweep (measured on MI355X: 3x3 filters peak
     // at 4-6 rows per band, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
@@ -674,7 +843,7 @@ int launch_filter(const FilterArgs& a)
     switch (a.filter) {
     case MI_FILTER_SOBEL:
     {
-#define MI_L(P) if (margin == 4) sobel_kernel<P, 4><<<grid, 256, 0, a.stream>>>(in, out, g); else sobel_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+#define MI_L(P) switch (env_int("MI_PF", 2)) { case 1: sobel_kernel<P, 1><<<grid, 256, 0, a.stream>>>(in, out, g); break; case 3: sobel_kernel<P, 3><<<grid, 256, 0, a.stream>>>(in, out, g); break; case 4: sobel_kernel<P, 4><<<grid, 256, 0, a.stream>>>(in, out, g); break; default: sobel_kernel<P, 2><<<grid, 256, 0, a.stream>>>(in, out, g); }
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }

@@ -29,6 +29,8 @@ struct FilterArgs {
 };
 int launch_filter(const FilterArgs& a);
 int filter_halo_rows(int filter, int ksize);
+// gray -> Gaussian 5x5 -> median 3x3 -> Sobel in one kernel (whole frames).
+int launch_chain(const void* in, void* out, int w, int h, int batch, float sigma, hipStream_t s);
 
 // generateGaussianKernal restated for the library (host code; imageTools.cu:362-385).
 void gaussian_kernel_2d(int k, float sigma, float* out);

@@ -96,6 +96,16 @@ def filter_chain(img, bufs=None, gauss_k=5, gauss_sigma=1.0, median_k=3):
     return bufs
 
 
+def fused_chain(img, gauss_sigma=1.0, out=None):
+    """The same chain in one kernel (mi_chain_gray_gauss5_median3_sobel_u8x4_dev): only the final
+    Sobel image is produced, bit-identical to filter_chain(img)[3]."""
+    w, h, b = _frames(img)
+    out = _out_like(img, out)
+    check(lib().mi_chain_gray_gauss5_median3_sobel_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, b,
+                                                            float(gauss_sigma), _stream()))
+    return out
+
+
 def filter_strip(filter_id, strip_in, out, w, h_total, in_row0, y_begin, y_end, ksize=3, sigma=0.0):
     """One row strip of a larger image (mi_filter_strip_u8x4_dev): strip_in holds global rows
     [in_row0, in_row0 + strip_in.shape[0]); out receives rows [y_begin, y_end)."""

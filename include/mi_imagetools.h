@@ -87,6 +87,16 @@ int mi_meanblur_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch,
 int mi_medianblur_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch,
                            int kernel_size, void *stream);
 
+/* The filter chain of BASELINE.json's headline config -- grayscale, Gaussian 5x5 (sigma), median
+ * 3x3, Sobel -- fused into one pass over the frames.  Output is bit-identical to calling
+ * mi_grayscale_u8x4_dev, mi_gaussian_u8x4_dev(5, sigma, MI_GAUSS_SEPARABLE),
+ * mi_medianblur_u8x4_dev(3) and mi_sobel_u8x4_dev in turn (i.e. to chaining the reference's
+ * imageGrayScaleWrapper, imageGaussianBlurWrapper, [median], imageSobelEdgeWrapper,
+ * main.cpp:38-42, with the Gaussian's +-1 LSB caveat); the intermediate images are never
+ * written.  Needs w >= 3 and h >= 3. */
+int mi_chain_gray_gauss5_median3_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h,
+                                                int batch, float sigma, void *stream);
+
 /* Row-strip variants for one image of w x h_total pixels split over several devices.
  * d_in holds global rows [in_row0, in_row0+in_rows) (the strip plus its halo), d_out receives
  * global rows [y_begin, y_end) starting at its row 0.  The halo must cover rows

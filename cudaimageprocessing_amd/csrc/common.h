@@ -120,7 +120,7 @@ MI_DEV WaveJob wave_job(const Geo& g)
     const int waves_per_block = blockDim.x >> 6;
     const u32 nblk = gridDim.x, b = blockIdx.x;
     const u32 q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    const u32 logical = (g.xcd_remap & 1) ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
+    const u32 logical = g.xcd_remap ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
     int wid = (int)logical * waves_per_block + (int)(threadIdx.x >> 6);
     wid = __builtin_amdgcn_readfirstlane(wid);
     WaveJob j;
@@ -238,25 +238,3 @@ struct RowIO<1> {
     }
 };
 
-// The rows a wave has asked for but not yet used: PF rows (main vector + one-hop halo) in flight.
-// One row in flight per wave is not enough to cover the HBM latency under load (8192 resident
-// waves x 1 KiB = 8 MB in flight ~ 2.6 TB/s x 3 us); PF rows multiply that.
-template <int POL, int PF>
-struct RowQueue {
-    u32x4 p[PF], h[PF];
-    // queue input steps first .. first+PF-1
-    MI_DEV void fill(const RowIO<POL>& io, const March& m, int first)
-    {
-#pragma unroll
-        for (int k = 0; k < PF; k++) { p[k] = io.load(m.row(first + k)); h[k] = io.load_halo(m.row(first + k), 1); }
-    }
-    // take the oldest row (input step `step`) and queue input step `step + PF`
-    MI_DEV void pop(const RowIO<POL>& io, const March& m, int step, u32x4& pv, u32x4& hv)
-    {
-        pv = p[0]; hv = h[0];
-#pragma unroll
-        for (int k = 0; k + 1 < PF; k++) { p[k] = p[k + 1]; h[k] = h[k + 1]; }
-        p[PF - 1] = io.load(m.row(step + PF));
-        h[PF - 1] = io.load_halo(m.row(step + PF), 1);
-    }
-};

@@ -92,7 +92,7 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
     const RowIO<POL> io(in, out, g, j, mch, j.strip * 256);                                      \
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)}
 
-template <int POL, int PF>
+template <int POL>
 __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
@@ -108,14 +108,13 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
     th = halo_red(io.load_halo(mch.row(-1), 1));
     red_pairs(io.load(mch.row(0)), m01, m23);
     mh = halo_red(io.load_halo(mch.row(0), 1));
-    RowQueue<POL, PF> q;
-    q.fill(io, mch, 1);
+    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
-        u32x4 nxt, nxh;
-        q.pop(io, mch, i + 1, nxt, nxh);
         red_pairs(nxt, b01, b23);
         bh = halo_red(nxh);
+        nxt = io.load(mch.row(i + 2));   // one row ahead; deeper prefetch measured no gain
+        nxh = io.load_halo(mch.row(i + 2), 1);
         const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
         const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
         const u32 VH = pk_add(pk_add(th, bh), pk_add(mh, mh));
@@ -141,9 +140,6 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
             const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
             o[k] = (sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)) * 0x010101u | 0xFF000000u) & xm[k] & rowm;
         }
-        if (g.xcd_remap & 2) {   // EXPERIMENT: memory structure only
-            io.store(y, u32x4{m01 ^ t01 ^ b01, m23 ^ t23 ^ b23, th ^ mh ^ bh, m01});
-        } else
         io.store(y, u32x4{o[0], o[1], o[2], o[3]});
         t01 = m01; t23 = m23; th = mh; m01 = b01; m23 = b23; mh = bh;
     }
@@ -761,7 +757,7 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     // early stages; shrink them only to fill the machine
     int rpb = env_int("MI_CHAIN_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
-        rpb = 64;
+        rpb = 60;
         while (rpb > 8 && (i64)batch * g.strips * ((H + rpb - 1) / rpb) < 8192) rpb >>= 1;
     }
     rpb = std::max(1, std::min(rpb, (int)((1LL << 28) / W)));
@@ -868,14 +864,14 @@ int launch_filter(const FilterArgs& a)
     const i64 total = (i64)a.batch * g.bands * g.strips;
     if (total > 0x7fffffff / 64) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
     g.total_waves = (int)total;
-    g.xcd_remap = env_int("MI_XCD_REMAP", 1);
+    g.xcd_remap = 1;
     const int pol = aligned ? 1 : 0;
     const int grid = (int)((total + 3) / 4);
 
     switch (a.filter) {
     case MI_FILTER_SOBEL:
     {
-#define MI_L(P) switch (env_int("MI_PF", 2)) { case 1: sobel_kernel<P, 1><<<grid, 256, 0, a.stream>>>(in, out, g); break; case 3: sobel_kernel<P, 3><<<grid, 256, 0, a.stream>>>(in, out, g); break; case 4: sobel_kernel<P, 4><<<grid, 256, 0, a.stream>>>(in, out, g); break; default: sobel_kernel<P, 2><<<grid, 256, 0, a.stream>>>(in, out, g); }
+#define MI_L(P) sobel_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }

@@ -72,7 +72,7 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     mode = sys.argv[2] if len(sys.argv) > 2 else "main"
     if mode == "main":
-        cfgs = [dict(MI_ROWS_PER_BAND=r, MI_XCD_REMAP=x, MI_PF=pf) for x in (1, 3) for pf in (1, 2, 3, 4) for r in (6, 8, 16, 32)]
+        cfgs = [dict(MI_ROWS_PER_BAND=r, MI_XCD_REMAP=x, MI_WPB=wpb, MI_PF=1) for x in (1, 3, 0, 2) for wpb in (1, 2, 4) for r in (6, 8)]
         sweep(FILTERS, cfgs)
     else:
         cfgs = [dict(MI_NT=1, MI_XCD_REMAP=x, MI_ROWS_PER_BAND=r) for x in (0, 1) for r in (8, 16, 32, 64)]

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One round's profile evidence for bench.py (run on the GPU box from the repo root):
+#   bash tools/profile_round.sh <tag>
+# 1. rocprofv3 --kernel-trace --stats of the default bench command  -> gpurun_out/<tag>_stats/
+# 2. FETCH_SIZE and WRITE_SIZE in separate --pmc passes              -> gpurun_out/<tag>_pmc_*/
+# 3. the per-kernel HBM traffic table + JSON                         -> gpurun_out/<tag>_traffic.{txt,json}
+set -u
+tag=$1
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+out=$root/gpurun_out
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats.log 2>&1 || { echo "stats pass failed"; tail -5 $out/${tag}_stats.log; exit 1; }
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/${tag}_pmc_$c.log; exit 1; }
+done
+python3 $root/tools/pmc_summary.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE --json $out/${tag}_traffic.json > $out/${tag}_traffic.txt
+cat $out/${tag}_traffic.txt
+f=$(find $out/${tag}_stats -name '*kernel_stats.csv' | head -1)
+cp "$f" $out/${tag}_kernel_stats.csv && cat $out/${tag}_kernel_stats.csv

@@ -23,13 +23,10 @@ px = B * W * H
 FILTERS = {
     "gray": lambda: ops.grayscale(frames, out),
     "sobel": lambda: ops.sobel(frames, out),
-}
-if os.environ.get("TUNE_ALL"):
-    FILTERS.update({
     "mean3": lambda: ops.mean_blur(frames, 3, out),
     "median3": lambda: ops.median_blur(frames, 3, out),
     "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),
-    })
+}
 EXTRA = {
     "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
     "gauss9": lambda: ops.gaussian_blur(frames, 9, 2.0, out),
@@ -72,8 +69,6 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     mode = sys.argv[2] if len(sys.argv) > 2 else "main"
     if mode == "main":
-        cfgs = [dict(MI_ROWS_PER_BAND=r, MI_XCD_REMAP=x, MI_WPB=wpb, MI_PF=1) for x in (1, 3, 0, 2) for wpb in (1, 2, 4) for r in (6, 8)]
-        sweep(FILTERS, cfgs)
+        sweep(FILTERS, [dict(MI_ROWS_PER_BAND=r) for r in (4, 6, 8, 12, 16, 24, 32)])
     else:
-        cfgs = [dict(MI_NT=1, MI_XCD_REMAP=x, MI_ROWS_PER_BAND=r) for x in (0, 1) for r in (8, 16, 32, 64)]
-        sweep(EXTRA, cfgs)
+        sweep(EXTRA, [dict(MI_ROWS_PER_BAND=r) for r in (8, 16, 32, 64)])

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mi_debug_sobel_mag_table_dev": [_vp, _u32, _vp],
     "mi_u8_to_complex_dev": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mi_fft2d_c2c_f32_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mi_fft2d_workspace_bytes": [_i, _i, _vp],
+    "mi_fft2d_c2c_f32_ws_dev": [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp],
     "mi_fftshift_dev": [_vp, _i, _i, _vp],
     "mi_highpass_dev": [_vp, _i, _i, _f, _vp],
     "mi_normalize_zero_imag_dev": [_vp, _i, _i, _vp],

@@ -320,6 +320,33 @@ int mi_fft2d_c2c_f32_dev(const void* d_in, void* d_out, int rows, int cols, int 
     return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream);
 }
 
+int mi_fft2d_workspace_bytes(int rows, int cols, size_t* bytes)
+{
+    if (!bytes) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (!fft2d_size_supported(rows, cols))
+        return fail(MI_ERR_UNSUPPORTED, "fft2d sizes must be in [2,4096] or a power of two up to 8192 (got %dx%d)", rows, cols);
+    *bytes = fft2d_workspace_bytes(rows, cols);
+    return MI_OK;
+}
+
+int mi_fft2d_c2c_f32_ws_dev(const void* d_in, void* d_out, int rows, int cols, int batch, int direction,
+                            void* d_workspace, size_t workspace_bytes, void* stream)
+{
+    if (!d_in || !d_out) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (batch <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive batch");
+    if (direction != MI_FFT_FORWARD && direction != MI_FFT_INVERSE) return fail(MI_ERR_INVALID_ARG, "direction must be -1 or +1");
+    size_t need = 0;
+    int rc = mi_fft2d_workspace_bytes(rows, cols, &need);
+    if (rc) return rc;
+    if (need && (!d_workspace || workspace_bytes < need))
+        return fail(MI_ERR_INVALID_ARG, "fft2d %dx%d needs a workspace of %zu bytes (got %zu)", rows, cols, need, d_workspace ? workspace_bytes : (size_t)0);
+    const size_t bytes = (size_t)rows * cols * 8 * batch;
+    if (d_in != d_out && overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping buffers");
+    if (need && (overlap(d_workspace, need, d_in, bytes) || overlap(d_workspace, need, d_out, bytes)))
+        return fail(MI_ERR_OVERLAP, "workspace overlaps the data");
+    return launch_fft2d_any(d_in, d_out, rows, cols, batch, direction, d_workspace, (hipStream_t)stream);
+}
+
 int mi_fftshift_dev(void* d_data, int w, int h, void* stream)
 {
     int rc = check_plane(d_data, w, h);
@@ -420,23 +447,29 @@ int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cu
     const size_t n = (size_t)w * h;
     void* d_img = nullptr;
     void* pl[3] = {nullptr, nullptr, nullptr};
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    rc = mi_fft2d_workspace_bytes(h, w, &ws_bytes);
+    if (rc) return rc;
     hipError_t e = hipMalloc(&d_img, n * 4);
+    if (e == hipSuccess && ws_bytes) e = hipMalloc(&ws, ws_bytes);
     for (int c = 0; c < 3 && e == hipSuccess; c++) e = hipMalloc(&pl[c], n * 8);
     if (e == hipSuccess) e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = mi_u8_to_complex_dev(d_img, pl[0], pl[1], pl[2], w, h, nullptr);
         for (int c = 0; c < 3 && rc == MI_OK; c++) {
-            rc = mi_fft2d_c2c_f32_dev(pl[c], pl[c], h, w, 1, MI_FFT_FORWARD, nullptr);
+            rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
             if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
             if (rc == MI_OK) rc = mi_highpass_dev(pl[c], w, h, cutoff, nullptr);
             if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
-            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_dev(pl[c], pl[c], h, w, 1, MI_FFT_INVERSE, nullptr);
+            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
             if (rc == MI_OK) rc = mi_normalize_zero_imag_dev(pl[c], w, h, nullptr);
         }
         if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl[0], pl[1], pl[2], d_img, w, h, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
     }
     if (d_img) (void)hipFree(d_img);
+    if (ws) (void)hipFree(ws);
     for (int c = 0; c < 3; c++) if (pl[c]) (void)hipFree(pl[c]);
     return rc ? rc : hip_status(e, "mi_fft_highpass_u8x4");
 }

@@ -476,4 +476,222 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
     return MI_OK;
 }
 
+
+// ================================================================ lengths that are not 2^k
+// The reference hands cuFFT whatever size the image has (its demo input is 675x900,
+// main.cpp:34-45), so the library does too: a line of n points, n not a power of two, is
+// transformed with Bluestein's chirp-z identity
+//     X[k] = w[k] * sum_j (x[j] w[j]) * conj(w)[k-j],      w[j] = exp(-i pi j^2 / n),
+// i.e. a cyclic convolution of length m = 2^p >= 2n-1 done with the power-of-two line
+// transform above: multiply by the chirp and zero-pad, FFT_m, multiply by FFT_m(conj chirp),
+// inverse FFT_m, multiply by the chirp / m.  j^2 is reduced mod 2n in integers and the chirp is
+// evaluated in double, so the only fp32 rounding is that of the two m-point transforms.
+// The column transform of such a plane goes through a transpose in the caller's workspace.
+
+static bool is_pow2(int n) { return n >= 2 && (n & (n - 1)) == 0; }
+static int blue_m(int n)            // 0: n is a power of two and needs no chirp
+{
+    if (is_pow2(n)) return 0;
+    int m = 2;
+    while (m < 2 * n - 1) m <<= 1;
+    return m;
+}
+
+// chirp[j] = exp(-i pi j^2 / n), j < n;  b[q] = conj(chirp[min(q, m-q)]) or 0, q < m
+__global__ void blue_tables_kernel(c2* __restrict__ chirp, c2* __restrict__ b, int n, int m)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const int d = q < m - q ? q : m - q;
+    c2 w{0.f, 0.f};
+    if (d < n) {
+        const unsigned long long r = ((unsigned long long)d * (unsigned long long)d) % (2ull * (unsigned long long)n);
+        double sn, cs;
+        sincospi((double)r / (double)n, &sn, &cs);
+        w = c2{(float)cs, (float)sn};                  // conj(chirp[d])
+    }
+    b[q] = w;
+    if (q < n) chirp[q] = c2{w.x, -w.y};
+}
+
+// pad[l][q] = q < n ? x[l][q] (conjugated for the inverse) * chirp[q] : 0
+__global__ __launch_bounds__(256) void blue_pre_kernel(const c2* __restrict__ src, i64 src_stride,
+                                                       c2* __restrict__ pad, const c2* __restrict__ chirp,
+                                                       int n, int m_log2, i64 total, int inverse)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i & ((1 << m_log2) - 1));
+    const i64 l = i >> m_log2;
+    c2 v{0.f, 0.f};
+    if (q < n) {
+        v = src[l * src_stride + q];
+        if (inverse) v.y = -v.y;
+        v = cmul(v, chirp[q]);
+    }
+    pad[i] = v;
+}
+
+__global__ __launch_bounds__(256) void blue_mul_kernel(c2* __restrict__ pad, const c2* __restrict__ bhat,
+                                                       int m_log2, i64 total)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    pad[i] = cmul(pad[i], bhat[(int)(i & ((1 << m_log2) - 1))]);
+}
+
+// dst[l][k] = pad[l][k] * chirp[k] / m  (conjugated for the inverse), k < n
+__global__ __launch_bounds__(256) void blue_post_kernel(const c2* __restrict__ pad, c2* __restrict__ dst,
+                                                        i64 dst_stride, const c2* __restrict__ chirp,
+                                                        int n, int m_log2, i64 total, float inv_m, int inverse)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % n);
+    const i64 l = i / n;
+    c2 v = cmul(pad[(l << m_log2) + k], chirp[k]);
+    v.x *= inv_m; v.y *= inv_m;
+    if (inverse) v.y = -v.y;
+    dst[l * dst_stride + k] = v;
+}
+
+// dst (cols x rows) = transpose of src (rows x cols); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_c2_kernel(const c2* __restrict__ src, c2* __restrict__ dst,
+                                                           int rows, int cols)
+{
+    __shared__ c2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int x = x0 + tx, y = y0 + ty + j;
+        if (x < cols && y < rows) tile[ty + j][tx] = src[(i64)y * cols + x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int y = y0 + tx, x = x0 + ty + j;
+        if (x < cols && y < rows) dst[(i64)x * rows + y] = tile[tx][ty + j];
+    }
+}
+
+static int grid_for(i64 total, int* grid)
+{
+    const i64 blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "fft launch too large");
+    *grid = (int)blocks;
+    return MI_OK;
+}
+
+// `nlines` lines of n = 2^k contiguous points each, line l at src + l*src_stride -> dst + l*dst_stride
+static int pow2_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int nlines, int n, int dir, hipStream_t s)
+{
+    FftGeo g;
+    g.inverse = dir > 0;
+    g.plane_stride = 0;
+    g.tw_step = 0;
+    g.inner_log2 = 0; g.groups_log2 = 30; g.line_stride = 0;      // line index == group index
+    g.in_group_stride = src_stride; g.out_group_stride = dst_stride;
+    g.in_elem_stride = g.out_elem_stride = 1;
+    const i64 max_stride = std::max(src_stride, dst_stride);
+    const i64 per_launch = std::max<i64>(1, std::min<i64>((((i64)1 << 31) - 1 - (i64)n * 8) / (max_stride * 8) , (i64)1 << 29));
+    for (i64 l0 = 0; l0 < nlines; l0 += per_launch) {
+        const int nl = (int)std::min<i64>(per_launch, nlines - l0);
+        g.total_lines = nl;
+        const u32 bytes = (u32)(((i64)(nl - 1) * max_stride + n) * 8);
+        int rc = launch_pass<false>(n, src + l0 * src_stride, dst + l0 * dst_stride, g, bytes, s);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
+struct BlueTables { const c2* chirp; const c2* bhat; int m; };
+
+// Any n: lines as above; `pad` holds nlines * m points when n is not a power of two.
+static int any_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int nlines, int n, int dir,
+                     const BlueTables& t, c2* pad, hipStream_t s)
+{
+    if (t.m == 0) return pow2_lines(src, src_stride, dst, dst_stride, nlines, n, dir, s);
+    const int m_log2 = __builtin_ctz(t.m);
+    const int inverse = dir > 0;
+    int grid = 0;
+    int rc = grid_for((i64)nlines * t.m, &grid);
+    if (rc) return rc;
+    blue_pre_kernel<<<grid, 256, 0, s>>>(src, src_stride, pad, t.chirp, n, m_log2, (i64)nlines * t.m, inverse);
+    rc = pow2_lines(pad, t.m, pad, t.m, nlines, t.m, -1, s);
+    if (rc) return rc;
+    blue_mul_kernel<<<grid, 256, 0, s>>>(pad, t.bhat, m_log2, (i64)nlines * t.m);
+    rc = pow2_lines(pad, t.m, pad, t.m, nlines, t.m, +1, s);
+    if (rc) return rc;
+    rc = grid_for((i64)nlines * n, &grid);
+    if (rc) return rc;
+    blue_post_kernel<<<grid, 256, 0, s>>>(pad, dst, dst_stride, t.chirp, n, m_log2, (i64)nlines * n, 1.0f / (float)t.m, inverse);
+    return hip_status(hipGetLastError(), "chirp-z kernel launch");
+}
+
+// Workspace layout, in complex points: [transposed plane | padded lines | chirp_c, bhat_c, chirp_r, bhat_r]
+struct BlueLayout { i64 plane_t, pad, tables, total; int mc, mr; };
+
+static BlueLayout blue_layout(int rows, int cols)
+{
+    BlueLayout L;
+    L.mc = blue_m(cols);
+    L.mr = blue_m(rows);
+    L.plane_t = (i64)rows * cols;
+    L.pad = std::max((i64)rows * L.mc, (i64)cols * L.mr);
+    L.tables = (i64)(L.mc ? cols + L.mc : 0) + (L.mr ? rows + L.mr : 0);
+    L.total = L.plane_t + L.pad + L.tables;
+    return L;
+}
+
+int fft2d_size_supported(int rows, int cols)
+{
+    auto ok = [](int n) { return n >= 2 && (n <= 4096 || (n <= 8192 && is_pow2(n))); };
+    return ok(rows) && ok(cols);
+}
+
+size_t fft2d_workspace_bytes(int rows, int cols)
+{
+    if (is_pow2(rows) && is_pow2(cols)) return 0;
+    return (size_t)blue_layout(rows, cols).total * sizeof(c2);
+}
+
+int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws, hipStream_t s)
+{
+    if (is_pow2(rows) && is_pow2(cols)) return launch_fft2d(in, out, rows, cols, batch, dir, s);
+    int rc = ensure_twiddles(s);
+    if (rc) return rc;
+    const BlueLayout L = blue_layout(rows, cols);
+    c2* plane_t = (c2*)ws;
+    c2* pad = plane_t + L.plane_t;
+    c2* tab = pad + L.pad;
+    BlueTables tc{nullptr, nullptr, L.mc}, tr{nullptr, nullptr, L.mr};
+    auto make_tables = [&](BlueTables& t, int n) -> int {
+        if (!t.m) return MI_OK;
+        c2* chirp = tab; c2* bhat = tab + n;
+        tab += n + t.m;
+        blue_tables_kernel<<<(t.m + 255) / 256, 256, 0, s>>>(chirp, bhat, n, t.m);
+        t.chirp = chirp; t.bhat = bhat;
+        return pow2_lines(bhat, t.m, bhat, t.m, 1, t.m, -1, s);
+    };
+    rc = make_tables(tc, cols);
+    if (rc == MI_OK) rc = make_tables(tr, rows);
+    if (rc) return rc;
+    const dim3 tgrid_fwd((cols + 31) / 32, (rows + 31) / 32), tgrid_back((rows + 31) / 32, (cols + 31) / 32);
+    const i64 plane = (i64)rows * cols;
+    for (int b = 0; b < batch; b++) {
+        const c2* pin = (const c2*)in + b * plane;
+        c2* pout = (c2*)out + b * plane;
+        rc = any_lines(pin, cols, pout, cols, rows, cols, dir, tc, pad, s);            // rows
+        if (rc) return rc;
+        transpose_c2_kernel<<<tgrid_fwd, 256, 0, s>>>(pout, plane_t, rows, cols);
+        rc = any_lines(plane_t, rows, plane_t, rows, cols, rows, dir, tr, pad, s);     // columns, as rows of the transpose
+        if (rc) return rc;
+        transpose_c2_kernel<<<tgrid_back, 256, 0, s>>>(plane_t, pout, cols, rows);
+        rc = hip_status(hipGetLastError(), "transpose kernel launch");
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 }  // namespace mi

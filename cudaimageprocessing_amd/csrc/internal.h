@@ -44,6 +44,12 @@ int launch_sobel_table(void* out, uint32_t count, hipStream_t s);
 // FFT path
 int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s);
+// Any sizes (powers of two up to 8192, anything else up to 4096) with a caller workspace of
+// fft2d_workspace_bytes(rows, cols) bytes (0 when both are powers of two).
+int fft2d_size_supported(int rows, int cols);
+size_t fft2d_workspace_bytes(int rows, int cols);
+int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws,
+                     hipStream_t s);
 int launch_fftshift(void* d, int w, int h, hipStream_t s);
 int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s);
 int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);

@@ -181,13 +181,31 @@ def u8_to_complex(img):
     return planes
 
 
-def fft2d(x, inverse=False, out=None):
-    """Unnormalised 2-D complex DFT of the last two dims (cufftExecC2C's convention)."""
+def fft2d_workspace_bytes(rows, cols):
+    """Device scratch a rows x cols transform needs (0 for powers of two)."""
+    import ctypes
+    n = ctypes.c_size_t(0)
+    check(lib().mi_fft2d_workspace_bytes(rows, cols, ctypes.byref(n)))
+    return int(n.value)
+
+
+def fft2d(x, inverse=False, out=None, workspace=None):
+    """Unnormalised 2-D complex DFT of the last two dims (cufftExecC2C's convention).  Sizes that
+    are not powers of two need scratch: `workspace` (a uint8 device tensor of at least
+    fft2d_workspace_bytes) or, when None, one allocated here through torch."""
     rows, cols, batch = _plane(x)
     if out is None:
         out = _torch().empty_like(x)
-    check(lib().mi_fft2d_c2c_f32_dev(x.data_ptr(), out.data_ptr(), rows, cols, batch,
-                                     _lib.FFT_INVERSE if inverse else _lib.FFT_FORWARD, _stream()))
+    direction = _lib.FFT_INVERSE if inverse else _lib.FFT_FORWARD
+    need = fft2d_workspace_bytes(rows, cols)
+    if need == 0:
+        check(lib().mi_fft2d_c2c_f32_dev(x.data_ptr(), out.data_ptr(), rows, cols, batch, direction, _stream()))
+        return out
+    if workspace is None:
+        workspace = _torch().empty(need, dtype=_torch().uint8, device=x.device)
+    check(lib().mi_fft2d_c2c_f32_ws_dev(x.data_ptr(), out.data_ptr(), rows, cols, batch, direction,
+                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                        _stream()))
     return out
 
 

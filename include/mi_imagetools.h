@@ -132,11 +132,20 @@ int mi_u8_to_complex_dev(const void *d_in, void *d_red, void *d_green, void *d_b
                          void *stream);
 /* cufftExecC2C (imageTools.cu:690-701, 741-751): unnormalised 2-D complex DFT, out of place or
  * in place, `batch` planes back to back.  direction -1 forward, +1 inverse.  rows and cols must
- * be powers of two in [2, 8192] in this build. */
+ * be powers of two in [2, 8192] for this entry point (no workspace). */
 #define MI_FFT_FORWARD (-1)
 #define MI_FFT_INVERSE (+1)
 int mi_fft2d_c2c_f32_dev(const void *d_in, void *d_out, int rows, int cols, int batch,
                          int direction, void *stream);
+/* cufftPlan2d + cufftExecC2C for any size (the reference plans whatever the image measures; its
+ * demo input is 675x900, main.cpp:34-45): each of rows, cols is in [2, 4096], or a power of two
+ * up to 8192.  Lengths that are not powers of two go through Bluestein's chirp-z transform and
+ * need device scratch: mi_fft2d_workspace_bytes gives the size (0 when both are powers of two),
+ * the caller owns the buffer (cuFFT keeps its work area inside the plan).  Calls sharing one
+ * workspace must be stream-ordered. */
+int mi_fft2d_workspace_bytes(int rows, int cols, size_t *bytes);
+int mi_fft2d_c2c_f32_ws_dev(const void *d_in, void *d_out, int rows, int cols, int batch,
+                            int direction, void *d_workspace, size_t workspace_bytes, void *stream);
 /* fftShift (imageTools.cu:564-583), in place. */
 int mi_fftshift_dev(void *d_data, int w, int h, void *stream);
 /* highpassFilter (imageTools.cu:530-549), in place, on a shifted spectrum. */

@@ -52,6 +52,59 @@ def test_fft2d_forward_and_inverse_match_oracle(dev, golden, rows, cols):
     assert rel_l2(y.cpu().numpy(), ref) <= REL_L2
 
 
+ODD_SHAPES = [(3, 5), (2, 7), (6, 10), (15, 17), (100, 64), (64, 100), (31, 1000), (243, 125),
+              (900, 675), (2000, 2592 // 2), (4096, 3), (5, 8192), (4095, 6)]
+
+
+@pytest.mark.parametrize("rows,cols", ODD_SHAPES)
+def test_fft2d_any_size_matches_dft(dev, golden, rows, cols):
+    """Sizes that are not powers of two (the reference's demo image is 675x900, main.cpp:34-45):
+    Bluestein path against the double-precision DFT (the oracle's O(n^2) definition for the small
+    cases, numpy.fft -- itself checked against the oracle in tests/test_oracle.py -- for the rest)."""
+    x = rand_plane(rows, cols, rows * 3 + cols)
+    xd = torch.from_numpy(x).to(dev)
+    if rows * cols <= 64 * 100:
+        ref_f = golden.fft2d_f64(x.astype(np.complex128), -1)
+        ref_i = golden.fft2d_f64(x.astype(np.complex128), +1)
+    else:
+        ref_f = np.fft.fft2(x.astype(np.complex128))
+        ref_i = np.fft.ifft2(x.astype(np.complex128)) * (rows * cols)
+    assert rel_l2(ops.fft2d(xd).cpu().numpy(), ref_f) <= REL_L2
+    assert rel_l2(ops.fft2d(xd, inverse=True).cpu().numpy(), ref_i) <= REL_L2
+    y = xd.clone()
+    ws = torch.empty(ops.fft2d_workspace_bytes(rows, cols), dtype=torch.uint8, device=dev)
+    ops.fft2d(y, out=y, workspace=ws)                                   # in place, caller's workspace
+    assert rel_l2(y.cpu().numpy(), ref_f) <= REL_L2
+
+
+def test_fft2d_any_size_batch_roundtrip_and_errors(dev):
+    x = rand_plane(90, 68, 11, batch=3)
+    xd = torch.from_numpy(x).to(dev)
+    f = ops.fft2d(xd)
+    for b in range(3):
+        assert torch.equal(f[b], ops.fft2d(xd[b].contiguous()))
+    back = ops.fft2d(f, inverse=True).cpu().numpy() / (90 * 68)
+    assert rel_l2(back, x) <= REL_L2
+    assert ops.fft2d_workspace_bytes(64, 128) == 0 and ops.fft2d_workspace_bytes(90, 68) > 0
+    with pytest.raises(_lib.MiError):
+        ops.fft2d_workspace_bytes(5000, 64)                             # > 4096 and not a power of two
+    with pytest.raises(_lib.MiError):
+        ops.fft2d(xd, workspace=torch.empty(16, dtype=torch.uint8, device=dev))
+    with pytest.raises(_lib.MiError):                                   # the no-workspace entry point stays 2^k only
+        _lib.check(_lib.lib().mi_fft2d_c2c_f32_dev(xd.data_ptr(), f.data_ptr(), 90, 68, 3, -1, None))
+
+
+def test_fft_highpass_image_any_size(dev, golden):
+    """imageFFTImageGenerate on an image shaped like the reference's demo input, scaled down."""
+    w, h = 135, 180
+    img = S.pattern_image("natural", w, h, 5)
+    out = np.empty_like(img)
+    ops.imageFFTImageGenerate(out, img, w, h)
+    ref_u8, _ = golden.fft_highpass_image(img, 10.0)
+    assert np.abs(out.astype(np.int16) - ref_u8.astype(np.int16)).max() <= 1
+    assert (out[..., 3] == 255).all()
+
+
 def test_fft2d_closed_forms(dev):
     n = 64
     imp = torch.zeros((n, n), dtype=torch.complex64, device=dev)

@@ -6,7 +6,7 @@
 // Build with -ffp-contract=off: every fused multiply-add is spelled out.
 #include "common.h"
 #include "internal.h"
-#include "median_network.h"
+#include "median5_network.h"
 
 namespace mi {
 
@@ -616,33 +616,106 @@ __global__ __launch_bounds__(256) void mean_generic_kernel(const u32* __restrict
     out[(i64)y * g.W + x - g.out_origin] = o;
 }
 
-// Median 5x5: 13th smallest of the 25 flat taps per channel, one pixel per lane, selection
-// network (median_network.h) on packed u16 pairs.
+// ============================================================================ median 5x5
+// 13th smallest of the 25 flat taps per channel, alpha 255, same write set as the other stencils.
+// Wave march with one margin lane on each side (62 productive lanes, like the fused chain).
+// Work shared between neighbouring outputs (networks in median5_network.h):
+//   * every 5-pixel column is sorted once per row (sort5);
+//   * adjacent sorted columns are merged pairwise (merge55) -- a lane merges its columns (0,1)
+//     and (2,3), the pair to its right arrives by DPP;
+//   * two outputs that share four columns share ranks 7..12 of those 20 values (ranks7to12):
+//     outputs 1,2 use the lane's own two pairs, output 3 and the right neighbour's output 0 use
+//     pair (2,3) and the neighbour's pair (0,1);
+//   * each output then picks the 6th smallest of those 6 values and its fifth column (select6of11).
+// R and B of a pixel share a register (one column per register); the G bytes of two adjacent
+// pixels share one, so a "column" of the G pass is a pair of columns (j, j+1) and its two halves
+// are outputs j and j+1 -- shifted pairs come from alignbit, as in the 3x3 kernel.
+template <int POL>
 __global__ __launch_bounds__(256) void median5_kernel(const u32* __restrict__ in,
                                                       u32* __restrict__ out, const Geo g)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = g.y_begin + blockIdx.y;
-    const int frame = blockIdx.z;
-    if (x >= g.W) return;
-    in += (i64)frame * g.in_frame_stride;
-    out += (i64)frame * g.out_frame_stride;
-    u32 o = 0;
-    if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2) {
-        u32 lo[25], hi[25];
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    constexpr int OUTW = 4 * 62;
+    const int cx = j.strip * OUTW - 4 + 4 * j.lane;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4, 1);
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    constexpr u32 SEL_G = 0x0c050c01u;   // (byte 1 of src1) | (byte 1 of src0) << 16
+    auto mn = [](u32 a, u32 b) { return pk_min(a, b); };
+    auto mx = [](u32 a, u32 b) { return pk_max(a, b); };
+
+    // slots 0..3 = (R | B << 16) of the lane's pixels, 4 = G of pixels 0,1, 5 = G of pixels 2,3
+    auto unpack = [&](u32x4 p, u32 (&w)[6]) {
+        w[0] = p.x & 0x00FF00FFu; w[1] = p.y & 0x00FF00FFu; w[2] = p.z & 0x00FF00FFu; w[3] = p.w & 0x00FF00FFu;
+        w[4] = __builtin_amdgcn_perm(p.y, p.x, SEL_G);
+        w[5] = __builtin_amdgcn_perm(p.w, p.z, SEL_G);
+    };
+
+    u32 win[5][6];   // ring: input step i lives in slot i % 5 (loop unrolled by 5: static indices)
 #pragma unroll
-        for (int ky = -2; ky <= 2; ky++)
+    for (int i = 0; i < 4; i++) unpack(io.load(mch.row(i - 2)), win[i]);
+    u32x4 nxt = io.load(mch.row(2));
+    for (int base = 0; base < mch.n; base += 5) {
 #pragma unroll
-            for (int kx = -2; kx <= 2; kx++) {
-                const u32 p = tap_px(in, g, (i64)(y + ky) * g.W + (x + kx));
-                unpack_px(p, lo[(ky + 2) * 5 + kx + 2], hi[(ky + 2) * 5 + kx + 2]);
+        for (int s = 0; s < 5; s++) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
+            unpack(nxt, win[(s + 4) % 5]);
+            nxt = io.load(mch.row(i + 3));
+            u32 c[6][5];   // sorted columns
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+#pragma unroll
+                for (int r = 0; r < 5; r++) c[k][r] = win[r][k];
+                sort5(c[k], mn, mx);
             }
-        struct CE { MI_DEV void operator()(u32& a, u32& b) const { sort2(a, b); } };
-        const u32 mlo = median25_select(lo, CE{});
-        const u32 mhi = median25_select(hi, CE{});
-        o = mlo | (mhi << 8) | 0xFF000000u;
+            u32 rb[4], g01, g23;
+            {   // ---- R,B
+                u32 m01[10], m23[10], rm01[10], sa[6], sb[6], lsb[6], lc3[5], rc0[5];
+                merge55(c[0], c[1], m01, mn, mx);
+                merge55(c[2], c[3], m23, mn, mx);
+#pragma unroll
+                for (int k = 0; k < 10; k++) rm01[k] = from_right(m01[k]);
+                ranks7to12(m01, m23, sa, mn, mx);      // columns 0..3
+                ranks7to12(m23, rm01, sb, mn, mx);     // columns 2..5
+#pragma unroll
+                for (int k = 0; k < 6; k++) lsb[k] = from_left(sb[k]);   // columns -2..1
+#pragma unroll
+                for (int k = 0; k < 5; k++) { lc3[k] = from_left(c[3][k]); rc0[k] = from_right(c[0][k]); }
+                rb[0] = select6of11(lsb, c[2], mn, mx);   // window -2..2
+                rb[1] = select6of11(sa, lc3, mn, mx);     // window -1..3
+                rb[2] = select6of11(sa, rc0, mn, mx);     // window  0..4
+                rb[3] = select6of11(sb, c[1], mn, mx);    // window  1..5
+            }
+            {   // ---- G: pair columns P_j = (column j, column j+1); own P0 = c[4], P2 = c[5]
+                u32 p1[5], p3[5], p4[5], n01[10], n23[10], ln23[10], s0[6], s2[6];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    p4[k] = from_right(c[4][k]);
+                    p1[k] = __builtin_amdgcn_alignbit(c[5][k], c[4][k], 16);
+                    p3[k] = __builtin_amdgcn_alignbit(p4[k], c[5][k], 16);
+                }
+                merge55(c[4], p1, n01, mn, mx);
+                merge55(c[5], p3, n23, mn, mx);
+#pragma unroll
+                for (int k = 0; k < 10; k++) ln23[k] = from_left(n23[k]);   // pair columns -2, -1
+                ranks7to12(ln23, n01, s0, mn, mx);
+                ranks7to12(n01, n23, s2, mn, mx);
+                g01 = select6of11(s0, c[5], mn, mx);      // pair columns -2..2: outputs 0, 1
+                g23 = select6of11(s2, p4, mn, mx);        // pair columns  0..4: outputs 2, 3
+            }
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            u32x4 o;
+            o.x = __builtin_amdgcn_perm(g01, rb[0], 0x0d020400u) & xm[0] & rowm;
+            o.y = __builtin_amdgcn_perm(g01, rb[1], 0x0d020600u) & xm[1] & rowm;
+            o.z = __builtin_amdgcn_perm(g23, rb[2], 0x0d020400u) & xm[2] & rowm;
+            o.w = __builtin_amdgcn_perm(g23, rb[3], 0x0d020600u) & xm[3] & rowm;
+            io.store(y, o);
+            }
+        }
     }
-    out[(i64)y * g.W + x - g.out_origin] = o;
 }
 
 // ============================================================================ utility kernels
@@ -818,8 +891,7 @@ int launch_filter(const FilterArgs& a)
     // generic one-thread-per-pixel kernels
     const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT;
     const bool mean_generic = a.filter == MI_FILTER_MEAN && a.ksize != 3;
-    const bool median5 = a.filter == MI_FILTER_MEDIAN && a.ksize == 5;
-    if (direct || mean_generic || median5) {
+    if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {
             const int nb = std::min(65535, a.batch - f0);
@@ -834,10 +906,8 @@ int launch_filter(const FilterArgs& a)
                     Weights2D wt;
                     gaussian_kernel_2d(a.ksize, a.sigma, wt.w);
                     gauss_direct_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize, wt);
-                } else if (mean_generic) {
-                    mean_generic_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize);
                 } else {
-                    median5_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg);
+                    mean_generic_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize);
                 }
             }
         }
@@ -845,7 +915,9 @@ int launch_filter(const FilterArgs& a)
     }
 
     // wave-march kernels
-    g.strips = (W + 255) / 256;   // a wave covers 64 lanes x 4 pixels
+    const bool median5 = a.filter == MI_FILTER_MEDIAN && a.ksize == 5;
+    // a wave covers 64 lanes x 4 pixels; the 5x5 median keeps one margin lane on each side
+    g.strips = median5 ? (W + 247) / 248 : (W + 255) / 256;
     // Rows per band.  Short bands keep the waves that run together on nearby rows, so the
     // access stream stays close to a front-to-back sweep (measured on MI355X: 3x3 filters peak
     // at 4-6 rows per band, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
@@ -855,6 +927,7 @@ int launch_filter(const FilterArgs& a)
     if (rpb <= 0) {
         const int r = a.filter == MI_FILTER_GAUSSIAN ? a.ksize / 2 : 1;
         rpb = r == 1 ? 6 : std::min(10 * r, 64);
+        if (median5) rpb = 32;   // VALU-bound: amortise the 4 extra rows of a band
         while (rpb > 4 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < 4096) rpb >>= 1;
     }
     // POL 1 addresses a band through 32-bit buffer offsets: keep a band under 1 GiB
@@ -885,7 +958,8 @@ int launch_filter(const FilterArgs& a)
         break;
     case MI_FILTER_MEDIAN:
     {
-#define MI_L(P) median3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+#define MI_L(P) if (median5) median5_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g); \
+                else median3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }

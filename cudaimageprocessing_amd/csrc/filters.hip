@@ -327,9 +327,14 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
 // alpha 255, flat-index taps.  Differences against the reference's 2-D summation order are
 // rounding only: max |delta| = 1 LSB after truncation.
 struct GaussW { float w[16]; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+MI_DEV f32x2 splat2(float v) { return f32x2{v, v}; }
 
+// A single wave per SIMD issues VALU work at about half rate on this part (tools/valubench.hip), so
+// the wide kernels, whose window would take the whole register file, are held to 256 registers
+// (two waves per SIMD); for R = 6, 7 that spills a few values to scratch and is still faster.
 template <int R, int POL>
-__global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ in,
+__global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const u32* __restrict__ in,
                                                         u32* __restrict__ out, const Geo g,
                                                         const GaussW gw)
 {
@@ -346,8 +351,10 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
         return r;
     };
 
-    // Row pass: h[3*k+c] = sum_t w[t] * channel c of column (k - R + t), k = 0..3.
-    auto hrow = [&](const RowIn& r, float (&h)[12]) {
+    // Row pass: h[3*p+c] = sum_t w[t] * channel c of columns (2p - R + t, 2p + 1 - R + t), p = 0,1:
+    // two adjacent output pixels per packed fp32 operation (v_pk_mul_f32 / v_pk_fma_f32, each
+    // half rounded exactly like the scalar operation).
+    auto hrow = [&](const RowIn& r, f32x2 (&h)[6]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         const u32 e1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
@@ -372,17 +379,18 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
             f[i][2] = (float)((v >> 16) & 0xffu);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float s = gw.w[0] * f[k][c];
+                f32x2 s = splat2(gw.w[0]) * f32x2{f[2 * q][c], f[2 * q + 1][c]};
 #pragma unroll
-                for (int t = 1; t < K; t++) s = __builtin_fmaf(gw.w[t], f[k + t][c], s);
-                h[3 * k + c] = s;
+                for (int t = 1; t < K; t++)
+                    s = __builtin_elementwise_fma(splat2(gw.w[t]), f32x2{f[2 * q + t][c], f[2 * q + 1 + t][c]}, s);
+                h[3 * q + c] = s;
             }
     };
 
-    float win[K][12];
+    f32x2 win[K][6];
     // input rows row(-R) .. row(R-1) fill slots 0 .. K-2 (the weights are symmetric, so the
     // marching direction does not matter to the column pass)
 #pragma unroll
@@ -402,20 +410,21 @@ __global__ __launch_bounds__(256) void gauss_sep_kernel(const u32* __restrict__ 
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float acc[3];
+            for (int q = 0; q < 2; q++) {
+                f32x2 acc[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     // centre tap, then the symmetric pairs (w[t] == w[K-1-t]): the sum does not
                     // depend on whether the band marches down or up, so any decomposition into
                     // bands or strips gives bit-identical output
-                    float a = gw.w[R] * win[(s + R) % K][3 * k + c];
+                    f32x2 a = splat2(gw.w[R]) * win[(s + R) % K][3 * q + c];
 #pragma unroll
                     for (int t = 0; t < R; t++)
-                        a = __builtin_fmaf(gw.w[t], win[(s + t) % K][3 * k + c] + win[(s + K - 1 - t) % K][3 * k + c], a);
+                        a = __builtin_elementwise_fma(splat2(gw.w[t]), win[(s + t) % K][3 * q + c] + win[(s + K - 1 - t) % K][3 * q + c], a);
                     acc[c] = a;
                 }
-                o[k] = ((u32)acc[0] | ((u32)acc[1] << 8) | ((u32)acc[2] << 16) | 0xFF000000u) & xm[k] & rowm;
+                o[2 * q] = ((u32)acc[0].x | ((u32)acc[1].x << 8) | ((u32)acc[2].x << 16) | 0xFF000000u) & xm[2 * q] & rowm;
+                o[2 * q + 1] = ((u32)acc[0].y | ((u32)acc[1].y << 8) | ((u32)acc[2].y << 16) | 0xFF000000u) & xm[2 * q + 1] & rowm;
             }
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
             }
@@ -928,7 +937,10 @@ int launch_filter(const FilterArgs& a)
         const int r = a.filter == MI_FILTER_GAUSSIAN ? a.ksize / 2 : 1;
         rpb = r == 1 ? 6 : std::min(10 * r, 64);
         if (median5) rpb = 32;   // VALU-bound: amortise the 4 extra rows of a band
-        while (rpb > 4 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < 4096) rpb >>= 1;
+        // wide Gaussians: 2R extra row passes per band, two waves per SIMD -> taller bands, fewer waves
+        const i64 min_waves = r >= 5 ? 2048 : 4096;
+        if (r >= 5) rpb = 128;
+        while (rpb > 4 && (i64)a.batch * g.strips * ((rows + rpb - 1) / rpb) < min_waves) rpb >>= 1;
     }
     // POL 1 addresses a band through 32-bit buffer offsets: keep a band under 1 GiB
     rpb = std::max(1, std::min(rpb, (int)((1LL << 28) / W)));

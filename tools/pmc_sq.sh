@@ -1,13 +1,13 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass with SQ occupancy/issue counters for the kernels of bench.py.
-# Usage: bash tools/pmc_sq.sh <tag> [ENV=VAL ...]
+# Usage: bash tools/pmc_sq.sh <tag> [ENV=VAL ...]   (PROG="tools/run_filter.py gauss15" profiles that instead)
 set -u
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out/pmc_${tag}_SQ
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out.log 2>&1 || { echo "pass failed"; tail -5 $out.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out -- python3 $root/${PROG:-bench.py --steps 2 --warmup 1 --no-cpu-baseline} > $out.log 2>&1 || { echo "pass failed"; tail -5 $out.log; exit 1; }
 python3 - $out <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

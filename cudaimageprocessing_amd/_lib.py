@@ -47,11 +47,19 @@ SIGNATURES = {
     "mi_gaussian_u8x4": [_vp, _vp, _i, _i, _i, _f, _i],
     "mi_meanblur_u8x4": [_vp, _vp, _i, _i, _i],
     "mi_medianblur_u8x4": [_vp, _vp, _i, _i, _i],
+    "mi_run_ops_u8x4": [_vp, _vp, _i, _i, _vp, _i],
+    "mi_run_ops_chunked_u8x4": [_vp, _vp, _i, _i, _vp, _i, _i],
+    "mi_host_release": [],
     "mi_fft_highpass_u8x4": [_vp, _vp, _i, _i, _f],
     "mi_gaussian_kernel": [_i, _f, _vp],
     "mi_version": [],
     "mi_device_count": [],
 }
+
+
+class Op(C.Structure):
+    """struct mi_op of include/mi_imagetools.h"""
+    _fields_ = [("filter", C.c_int), ("ksize", C.c_int), ("sigma", C.c_float)]
 
 
 class MiError(RuntimeError):

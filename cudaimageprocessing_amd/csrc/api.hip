@@ -117,27 +117,26 @@ static int run_frames(int filter, const void* in, void* out, int w, int h, int b
     return launch_filter(a);
 }
 
-// Host tier: the reference wrapper's shape (kernels/imageTools.cu:233-253): device buffers,
-// H2D, kernel, D2H, free -- on one stream, blocking until `out` holds the result.
-static int run_host(int filter, const uint8_t* in, uint8_t* out, int w, int h, int ksize, float sigma)
+// Host tier: the reference wrapper's shape (kernels/imageTools.cu:233-253): H2D, kernel(s), D2H,
+// blocking until `out` holds the result -- run as the chunked pipeline of host.hip.
+static int run_host_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows)
 {
     int rc = check_image(in, out, w, h, 1);
     if (rc) return rc;
-    rc = check_filter(filter, w, h, ksize, sigma);
-    if (rc) return rc;
-    const size_t bytes = (size_t)w * h * 4;
-    void *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc(&d_in, bytes);
-    if (e == hipSuccess) e = hipMalloc(&d_out, bytes);
-    if (e == hipSuccess) e = hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = run_frames(filter, d_in, d_out, w, h, 1, ksize, sigma, nullptr);
-        if (rc == MI_OK) e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost);
+    if (!ops || n_ops <= 0 || n_ops > MI_MAX_OPS) return fail(MI_ERR_INVALID_ARG, "need 1..%d ops (got %d)", MI_MAX_OPS, n_ops);
+    for (int k = 0; k < n_ops; k++) {
+        rc = check_filter(ops[k].filter, w, h, ops[k].ksize, ops[k].sigma);
+        if (rc) return rc;
     }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (rc) return rc;
-    return hip_status(e, "host-tier filter");
+    const size_t bytes = (size_t)w * h * 4;
+    if (in != out && overlap(in, bytes, out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping host buffers");
+    return host_run_ops(in, out, w, h, ops, n_ops, chunk_rows);
+}
+
+static int run_host(int filter, const uint8_t* in, uint8_t* out, int w, int h, int ksize, float sigma)
+{
+    const mi_op op = {filter, ksize, sigma};
+    return run_host_ops(in, out, w, h, &op, 1, 0);
 }
 
 // ---------------------------------------------------------------- PNG (RGBA8, zlib deflate)
@@ -439,6 +438,19 @@ int mi_medianblur_u8x4(const uint8_t* in, uint8_t* out, int w, int h, int kernel
 {
     return run_host(MI_FILTER_MEDIAN, in, out, w, h, kernel_size, 0.f);
 }
+
+int mi_run_ops_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops)
+{
+    return run_host_ops(in, out, w, h, ops, n_ops, 0);
+}
+
+int mi_run_ops_chunked_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows)
+{
+    if (chunk_rows <= 0) return fail(MI_ERR_INVALID_ARG, "chunk_rows must be positive");
+    return run_host_ops(in, out, w, h, ops, n_ops, chunk_rows);
+}
+
+int mi_host_release(void) { return host_release(); }
 
 int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)
 {

@@ -1,0 +1,165 @@
+// host.hip -- the blocking host tier for the u8x4 filters: what the reference's wrappers do
+// (kernels/imageTools.cu:233-253 and siblings: device buffers, H2D, kernel, D2H, free), as a
+// pipeline.  The image is cut into row chunks; a chunk is staged into pinned memory, copied to
+// the device, run through the whole list of filters on the device (each stage's row range shrinks
+// by that filter's halo) and copied back, on one of two streams, while the host stages the next
+// chunk and unloads the previous one.  Pinned and device buffers are kept between calls.
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "internal.h"
+
+namespace mi {
+
+namespace {
+
+struct Slot {
+    void* pin_in = nullptr;
+    void* pin_out = nullptr;
+    void* dev[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+struct HostPipe {
+    std::mutex mu;
+    int device = -1;
+    size_t cap_in = 0, cap_out = 0, cap_dev = 0;
+    Slot slot[2];
+
+    void release()
+    {
+        for (Slot& s : slot) {
+            if (s.pin_in) (void)hipHostFree(s.pin_in);
+            if (s.pin_out) (void)hipHostFree(s.pin_out);
+            for (void*& d : s.dev) { if (d) (void)hipFree(d); d = nullptr; }
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            s = Slot();
+        }
+        cap_in = cap_out = cap_dev = 0;
+        device = -1;
+    }
+
+    hipError_t reserve(size_t in_bytes, size_t out_bytes, size_t dev_bytes)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev != device) { release(); device = dev; }
+        for (Slot& s : slot) {
+            if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+            if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if (in_bytes > cap_in) {
+            for (Slot& s : slot) {
+                if (s.pin_in) (void)hipHostFree(s.pin_in);
+                s.pin_in = nullptr;
+                if ((e = hipHostMalloc(&s.pin_in, in_bytes, hipHostMallocDefault)) != hipSuccess) { cap_in = 0; return e; }
+            }
+            cap_in = in_bytes;
+        }
+        if (out_bytes > cap_out) {
+            for (Slot& s : slot) {
+                if (s.pin_out) (void)hipHostFree(s.pin_out);
+                s.pin_out = nullptr;
+                if ((e = hipHostMalloc(&s.pin_out, out_bytes, hipHostMallocDefault)) != hipSuccess) { cap_out = 0; return e; }
+            }
+            cap_out = out_bytes;
+        }
+        if (dev_bytes > cap_dev) {
+            for (Slot& s : slot)
+                for (void*& d : s.dev) {
+                    if (d) (void)hipFree(d);
+                    d = nullptr;
+                    if ((e = hipMalloc(&d, dev_bytes)) != hipSuccess) { cap_dev = 0; return e; }
+                }
+            cap_dev = dev_bytes;
+        }
+        return hipSuccess;
+    }
+};
+
+HostPipe g_pipe;
+
+struct Rows { int lo, hi; };
+
+}  // namespace
+
+int host_release()
+{
+    std::lock_guard<std::mutex> lock(g_pipe.mu);
+    g_pipe.release();
+    return MI_OK;
+}
+
+// ops are validated by the caller (api.hip).
+int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows_hint)
+{
+    const size_t pitch = (size_t)w * 4;
+    int halo_sum = 0;
+    for (int k = 0; k < n_ops; k++) halo_sum += filter_halo_rows(ops[k].filter, ops[k].ksize);
+    // chunk: about 8 MiB of output rows, never fewer rows than the accumulated halo (so that a
+    // chunk's input never reaches into rows an earlier chunk may already have overwritten when
+    // `out` aliases `in`, see below)
+    int chunk = chunk_rows_hint > 0 ? chunk_rows_hint : (int)std::max<size_t>(1, ((size_t)8 << 20) / pitch);
+    chunk = std::min(h, std::max(chunk, std::max(halo_sum, 1)));
+    const int n_chunks = (h + chunk - 1) / chunk;
+    const size_t in_rows_max = (size_t)std::min(h, chunk + 2 * halo_sum);
+
+    std::lock_guard<std::mutex> lock(g_pipe.mu);
+    hipError_t e = g_pipe.reserve(in_rows_max * pitch, (size_t)chunk * pitch, in_rows_max * pitch);
+    if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
+
+    std::vector<Rows> need(n_ops + 1);
+    int rc = MI_OK;
+    Rows pending{0, 0};          // output rows of the previous chunk, still in its slot's pin_out
+    auto unload = [&](int slot_id, Rows r) -> hipError_t {
+        hipError_t err = hipEventSynchronize(g_pipe.slot[slot_id].done);
+        if (err == hipSuccess) memcpy(out + (size_t)r.lo * pitch, g_pipe.slot[slot_id].pin_out, (size_t)(r.hi - r.lo) * pitch);
+        return err;
+    };
+    for (int c = 0; c < n_chunks && rc == MI_OK && e == hipSuccess; c++) {
+        Slot& s = g_pipe.slot[c & 1];
+        // rows each stage must produce, back to front
+        need[n_ops] = Rows{c * chunk, std::min(h, (c + 1) * chunk)};
+        for (int k = n_ops - 1; k >= 0; k--) {
+            const int halo = filter_halo_rows(ops[k].filter, ops[k].ksize);
+            need[k] = Rows{std::max(0, need[k + 1].lo - halo), std::min(h, need[k + 1].hi + halo)};
+        }
+        // stage the input rows (the slot's previous occupant, chunk c-2, was unloaded already).
+        // When out aliases in, this must precede the unload of chunk c-1, whose rows it may read.
+        memcpy(s.pin_in, in + (size_t)need[0].lo * pitch, (size_t)(need[0].hi - need[0].lo) * pitch);
+        e = hipMemcpyAsync(s.dev[0], s.pin_in, (size_t)(need[0].hi - need[0].lo) * pitch, hipMemcpyHostToDevice, s.stream);
+        int cur = 0;
+        for (int k = 0; k < n_ops && rc == MI_OK && e == hipSuccess; k++) {
+            FilterArgs a;
+            a.filter = ops[k].filter;
+            if (a.filter == MI_FILTER_GAUSSIAN && ops[k].ksize == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+            a.in = s.dev[cur]; a.out = s.dev[cur ^ 1]; a.w = w; a.h_total = h; a.batch = 1;
+            a.in_row0 = need[k].lo; a.in_rows = need[k].hi - need[k].lo;
+            a.y_begin = need[k + 1].lo; a.y_end = need[k + 1].hi;
+            a.ksize = ops[k].ksize; a.sigma = ops[k].sigma; a.stream = s.stream;
+            rc = launch_filter(a);
+            cur ^= 1;
+        }
+        if (rc == MI_OK && e == hipSuccess)
+            e = hipMemcpyAsync(s.pin_out, s.dev[cur], (size_t)(need[n_ops].hi - need[n_ops].lo) * pitch, hipMemcpyDeviceToHost, s.stream);
+        if (rc == MI_OK && e == hipSuccess) e = hipEventRecord(s.done, s.stream);
+        // while the device works on chunk c: unload chunk c-1
+        if (rc == MI_OK && e == hipSuccess && c > 0) e = unload((c - 1) & 1, pending);
+        pending = need[n_ops];
+    }
+    if (rc == MI_OK && e == hipSuccess) e = unload((n_chunks - 1) & 1, pending);
+    if (rc != MI_OK || e != hipSuccess) {
+        // leave nothing in flight that still points at the staging buffers
+        for (Slot& s : g_pipe.slot) if (s.stream) (void)hipStreamSynchronize(s.stream);
+    }
+    if (rc) return rc;
+    return hip_status(e, "host-tier filter pipeline");
+}
+
+}  // namespace mi

@@ -41,6 +41,12 @@ int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 int launch_synth(void* out, uint64_t seed, uint64_t first, uint64_t count, hipStream_t s);
 int launch_sobel_table(void* out, uint32_t count, hipStream_t s);
 
+// Host tier (host.hip): run `n_ops` filters over a host image through the staging pipeline;
+// chunk_rows_hint <= 0 picks the chunk height.  host_release frees the cached buffers.
+int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops,
+                 int chunk_rows_hint);
+int host_release();
+
 // FFT path
 int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s);

@@ -297,6 +297,38 @@ def imageMedianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize=3
                                    width, height, int(kernalSize)))
 
 
+_OP_NAMES = {"gray": _lib.FILTER_GRAYSCALE, "grayscale": _lib.FILTER_GRAYSCALE, "sobel": _lib.FILTER_SOBEL,
+             "gauss": _lib.FILTER_GAUSSIAN, "gaussian": _lib.FILTER_GAUSSIAN, "gauss_direct": _lib.FILTER_GAUSSIAN_DIRECT,
+             "mean": _lib.FILTER_MEAN, "median": _lib.FILTER_MEDIAN}
+
+
+def parse_ops(spec):
+    """'gray,gauss:5:1.0,median:3,sobel' -> [(filter, ksize, sigma)] (the demo CLI's syntax)."""
+    out = []
+    for item in spec.split(","):
+        parts = item.strip().split(":")
+        if parts[0] not in _OP_NAMES:
+            raise ValueError(f"unknown op {parts[0]!r} (known: {', '.join(sorted(_OP_NAMES))})")
+        f = _OP_NAMES[parts[0]]
+        ksize = int(parts[1]) if len(parts) > 1 else (0 if f == _lib.FILTER_GRAYSCALE else 3)
+        sigma = float(parts[2]) if len(parts) > 2 else 1.0
+        out.append((f, ksize, sigma))
+    return out
+
+
+def run_ops(returnImage, imageLoaded, width, height, ops_list, chunk_rows=None):
+    """Several filters on one host image in a single trip over PCIe (mi_run_ops_u8x4).
+    ops_list: [(filter, ksize, sigma)] or a parse_ops string."""
+    if isinstance(ops_list, str):
+        ops_list = parse_ops(ops_list)
+    arr = (_lib.Op * len(ops_list))(*[_lib.Op(int(f), int(k), float(s)) for f, k, s in ops_list])
+    src, dst = _host_img(imageLoaded, width, height), _host_img(returnImage, width, height)
+    if chunk_rows is None:
+        check(lib().mi_run_ops_u8x4(src, dst, width, height, arr, len(ops_list)))
+    else:
+        check(lib().mi_run_ops_chunked_u8x4(src, dst, width, height, arr, len(ops_list), int(chunk_rows)))
+
+
 def imageFFTImageGenerate(returnImage, imageLoaded, width, height, cutoff=10.0):
     check(lib().mi_fft_highpass_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
                                      width, height, float(cutoff)))

@@ -179,6 +179,26 @@ int mi_gaussian_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_s
 int mi_meanblur_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_size);
 /* Median blur (README.md:3; no reference code) */
 int mi_medianblur_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int kernel_size);
+/* A list of filters run back to back on one host image -- what the reference's demo does with
+ * consecutive wrapper calls on (img, img) (main.cpp:38-43) -- in ONE trip over PCIe: the image is
+ * cut into row chunks that are staged through pinned memory, copied, filtered by every stage on
+ * the device and copied back on alternating streams, overlapped with the host-side staging of
+ * the neighbouring chunks.  `out` may be `in`.  The result is bit-identical to calling the
+ * single-filter wrappers one after the other.  sigma is read by MI_FILTER_GAUSSIAN(_DIRECT)
+ * only, ksize by the Gaussian, mean and median.  The single-filter wrappers above run through
+ * the same pipeline.  Staging buffers are cached between calls (host-tier calls of one process
+ * serialise on them); mi_host_release frees them. */
+#define MI_MAX_OPS 16
+typedef struct mi_op {
+    int filter;  /* MI_FILTER_* */
+    int ksize;
+    float sigma;
+} mi_op;
+int mi_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *ops, int n_ops);
+/* The same with the chunk height chosen by the caller (tests; tuning). */
+int mi_run_ops_chunked_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *ops,
+                            int n_ops, int chunk_rows);
+int mi_host_release(void);
 /* imageFFTImageGenerate (imageTools.cu:633-791) without its debug means; cutoff is the
  * reference's hard-coded 10.0f (:716). */
 int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);

@@ -1,0 +1,154 @@
+"""GPU tests of the host tier's staging pipeline (mi_run_ops_u8x4 and the single-filter wrappers
+that run through it): chunked, double-buffered H2D / kernels / D2H must give exactly what the
+whole-image device path and the CPU oracle give, for any chunk height, with `out` aliasing `in`
+as the reference's demo calls its wrappers (main.cpp:38-43).  Also BASELINE.json config 1: the
+reference's own sample image, decoded on the host, gray + Gaussian 5x5, PNG out."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from cudaimageprocessing_amd import _lib, ops, synth as S  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def device_chain(img, op_list, dev):
+    """The same filters through the device tier, whole image, one launch per filter."""
+    x = torch.from_numpy(img).to(dev)
+    for f, k, s in op_list:
+        if f == _lib.FILTER_GRAYSCALE:
+            x = ops.grayscale(x)
+        elif f == _lib.FILTER_SOBEL:
+            x = ops.sobel(x)
+        elif f == _lib.FILTER_GAUSSIAN:
+            x = ops.gaussian_blur(x, k, s)
+        elif f == _lib.FILTER_GAUSSIAN_DIRECT:
+            x = ops.gaussian_blur(x, k, s, direct=True)
+        elif f == _lib.FILTER_MEAN:
+            x = ops.mean_blur(x, k)
+        elif f == _lib.FILTER_MEDIAN:
+            x = ops.median_blur(x, k)
+    return x.cpu().numpy()
+
+
+CHAINS = ["gray", "sobel", "gray,gauss:5:1.0,median:3,sobel", "gauss:15:2.5,median:5",
+          "mean:3,mean:7,gauss_direct:3:7.0", "median:5,gray,sobel,median:3,gauss:9:2.0"]
+
+
+@pytest.mark.parametrize("spec", CHAINS)
+@pytest.mark.parametrize("w,h,chunk", [(67, 45, 1), (67, 45, 7), (256, 96, 16), (250, 131, 40), (64, 30, 1000)])
+def test_pipeline_equals_whole_image(dev, spec, w, h, chunk):
+    img = S.pattern_image("natural", w, h, 7)
+    op_list = ops.parse_ops(spec)
+    want = device_chain(img, op_list, dev)
+    out = np.empty_like(img)
+    ops.run_ops(out, img, w, h, op_list, chunk_rows=chunk)
+    assert np.array_equal(out, want)
+    # in place, as the reference's demo calls its wrappers
+    buf = img.copy()
+    ops.run_ops(buf, buf, w, h, op_list, chunk_rows=chunk)
+    assert np.array_equal(buf, want)
+
+
+def test_pipeline_against_oracle(dev, golden):
+    w, h = 320, 200
+    img = S.synth_image(3, w, h)
+    out = np.empty_like(img)
+    ops.run_ops(out, img, w, h, "gray,gauss:5:1.0,median:3,sobel", chunk_rows=23)
+    g = golden.grayscale(img)
+    g = golden.gaussian(g, 5, 1.0)
+    # separable vs the reference's direct 2-D sum: +-1 LSB after the Gaussian, so compare from
+    # the library's own Gaussian output on (the later stages are exact)
+    lib_gauss = np.empty_like(img)
+    ops.run_ops(lib_gauss, img, w, h, "gray,gauss:5:1.0", chunk_rows=50)
+    assert np.abs(lib_gauss.astype(np.int16) - g.astype(np.int16)).max() <= 1
+    want = golden.sobel(golden.medianblur(lib_gauss, 3))
+    assert np.array_equal(out, want)
+
+
+def test_default_chunking_large_image(dev):
+    """Default chunk height (about 8 MiB): several chunks on a 4096 x 3000 image."""
+    w, h = 4096, 3000
+    img = ops.synth(9, w, h).cpu().numpy()
+    op_list = ops.parse_ops("gauss:5:1.0,median:3,sobel")
+    want = device_chain(img, op_list, dev)
+    buf = img.copy()
+    ops.run_ops(buf, buf, w, h, op_list)
+    assert np.array_equal(buf, want)
+    single = np.empty_like(img)
+    ops.imageMedianBlurWrapper(single, img, w, h, 5)
+    assert np.array_equal(single, device_chain(img, [(_lib.FILTER_MEDIAN, 5, 0.0)], dev))
+    _lib.check(_lib.lib().mi_host_release())
+    ops.imageSobelEdgeWrapper(single, img, w, h)                      # buffers come back after a release
+    assert np.array_equal(single, device_chain(img, [(_lib.FILTER_SOBEL, 3, 0.0)], dev))
+
+
+def test_run_ops_argument_errors(dev):
+    img = np.zeros((8, 8, 4), np.uint8)
+    with pytest.raises(_lib.MiError):
+        ops.run_ops(img, img, 8, 8, [])
+    with pytest.raises(_lib.MiError):
+        ops.run_ops(img, img, 8, 8, [(_lib.FILTER_MEDIAN, 7, 0.0)])
+    with pytest.raises(_lib.MiError):
+        ops.run_ops(img, img, 8, 8, [(_lib.FILTER_SOBEL, 3, 0.0)], chunk_rows=0)
+    with pytest.raises(ValueError):
+        ops.parse_ops("sharpen")
+
+
+def _png_pixels(path):
+    """Minimal reader for the PNGs mi_image_write produces (8-bit RGBA, filter 0, one IDAT)."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        tag = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) == int.from_bytes(data[pos + 8 + n:pos + 12 + n], "big")
+        if tag == b"IHDR":
+            w, h = int.from_bytes(body[:4], "big"), int.from_bytes(body[4:8], "big")
+            assert body[8:] == bytes([8, 6, 0, 0, 0])
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+def test_config1_sample_image_gray_gauss_png(dev, golden, tmp_path):
+    """BASELINE.json config 1: the reference's image/deer.jpeg (tests/golden/deer.jpeg, 2592x2000),
+    gray -> Gaussian 5x5 sigma 1.0 -> PNG.  JPEG decoding is host-side work outside the path
+    (stb_image upstream, Pillow here)."""
+    Image = pytest.importorskip("PIL.Image")
+    rgba = np.ascontiguousarray(np.asarray(Image.open(os.path.join(HERE, "golden", "deer.jpeg")).convert("RGBA")))
+    h, w = rgba.shape[:2]
+    assert (w, h) == (2592, 2000)
+    loaded = np.empty_like(rgba)
+    ops.imageLoadWrapper(rgba, loaded, w * h)
+    assert np.array_equal(loaded, rgba)
+    out = np.empty_like(rgba)
+    ops.run_ops(out, loaded, w, h, "gray,gauss:5:1.0")
+    ref = golden.gaussian(golden.grayscale(rgba, threads=8), 5, 1.0, threads=8)
+    diff = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    assert diff.max() <= 1
+    gray = np.empty_like(rgba)
+    ops.imageGrayScaleWrapper(gray, loaded, w, h)
+    assert np.array_equal(gray, golden.grayscale(rgba, threads=8))
+    path = str(tmp_path / "deer_blur.png")
+    ops.imageWriteWrapper(path, out, w, h)
+    assert np.array_equal(_png_pixels(path), out)
+    assert np.array_equal(np.asarray(Image.open(path)), out)

@@ -452,7 +452,10 @@ int mi_run_ops_chunked_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const
 
 int mi_host_release(void) { return host_release(); }
 
-int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)
+// imageFFTImageGenerate's scaffold (imageTools.cu:633-791): u8 -> three complex planes -> forward
+// transform -> `edit` on each spectrum -> inverse -> /N, imaginary part dropped -> u8.
+extern "C++" template <class Edit>
+static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edit edit)
 {
     int rc = check_image(in, out, w, h, 1);
     if (rc) return rc;
@@ -471,9 +474,7 @@ int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cu
         rc = mi_u8_to_complex_dev(d_img, pl[0], pl[1], pl[2], w, h, nullptr);
         for (int c = 0; c < 3 && rc == MI_OK; c++) {
             rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
-            if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
-            if (rc == MI_OK) rc = mi_highpass_dev(pl[c], w, h, cutoff, nullptr);
-            if (rc == MI_OK) rc = mi_fftshift_dev(pl[c], w, h, nullptr);
+            if (rc == MI_OK) rc = edit(pl[c]);
             if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
             if (rc == MI_OK) rc = mi_normalize_zero_imag_dev(pl[c], w, h, nullptr);
         }
@@ -483,7 +484,40 @@ int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cu
     if (d_img) (void)hipFree(d_img);
     if (ws) (void)hipFree(ws);
     for (int c = 0; c < 3; c++) if (pl[c]) (void)hipFree(pl[c]);
-    return rc ? rc : hip_status(e, "mi_fft_highpass_u8x4");
+    return rc ? rc : hip_status(e, "spectral round trip");
+}
+
+int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)
+{
+    if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
+    return spectral_roundtrip(in, out, w, h, [&](void* plane) {
+        int rc = mi_fftshift_dev(plane, w, h, nullptr);
+        if (rc == MI_OK) rc = mi_highpass_dev(plane, w, h, cutoff, nullptr);
+        if (rc == MI_OK) rc = mi_fftshift_dev(plane, w, h, nullptr);
+        return rc;
+    });
+}
+
+static size_t keep_count(size_t n, float keep_fraction)
+{
+    const double k = ceil((double)keep_fraction * (double)n);
+    return (size_t)std::min<double>((double)n, std::max<double>(1.0, k));
+}
+
+int mi_compress_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float keep_fraction)
+{
+    if (!(keep_fraction > 0.0f) || !(keep_fraction <= 1.0f))
+        return fail(MI_ERR_INVALID_ARG, "keep_fraction must be in (0, 1] (got %g)", (double)keep_fraction);
+    const size_t n = (size_t)w * h;
+    return spectral_roundtrip(in, out, w, h, [&](void* plane) {
+        return spectrum_keep_top(plane, n, keep_count(n, keep_fraction), nullptr);
+    });
+}
+
+int mi_spectrum_keep_top_dev(void* d_data, size_t n, size_t keep, void* stream)
+{
+    if (!d_data || n == 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
+    return spectrum_keep_top(d_data, n, keep, (hipStream_t)stream);
 }
 
 int mi_gaussian_kernel(int kernel_size, float sigma, float* out)

@@ -55,6 +55,16 @@ void imageFFTImageGenerate(uchar4* returnImage, uchar4* imageLoaded, int width, 
     check(mi_fft_highpass_u8x4((const uint8_t*)imageLoaded, (uint8_t*)returnImage, width, height, 10.0f), "imageFFTImageGenerate");
 }
 
+void compressImage(uchar4* outputImage, uchar4* inputImage, int width, int height)
+{   // never defined upstream; see mi_compress_u8x4 for the definition used here
+    check(mi_compress_u8x4((const uint8_t*)inputImage, (uint8_t*)outputImage, width, height, MI_COMPRESS_DEFAULT_KEEP), "compressImage");
+}
+
+bool test()
+{   // never defined upstream; the library's self-test
+    return mi_selftest() == MI_OK;
+}
+
 float* generateGaussianKernal(int kernalSize, float sigma)
 {
     float* k = (float*)malloc((size_t)kernalSize * kernalSize * sizeof(float));

@@ -1,6 +1,8 @@
 // spectral.hip -- the pointwise kernels of the reference's FFT demo path
 // (imageFFTImageGenerate, kernels/imageTools.cu:633-791) and the normalise helpers (:416-471).
 // The 2-D transform itself lives in fft.hip.
+#include <vector>
+
 #include "common.h"
 #include "internal.h"
 
@@ -205,6 +207,86 @@ int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* min
 {
     normalize_to_u8_kernel<<<flat_grid((i64)n), 256, 0, s>>>((const float*)img, (u32*)out, (i64)n, (const float*)minmax);
     return hip_status(hipGetLastError(), "normalize_to_u8 launch");
+}
+
+
+// ---------------------------------------------------------------- compressImage support
+// Keep the `keep` coefficients of largest |X|^2 of a spectrum and zero the rest: the threshold
+// is the keep-th largest value, found exactly by a two-level radix select on the bit pattern of
+// |X|^2 (non-negative floats order like unsigned integers): a histogram of the upper 16 bits,
+// then of the lower 16 bits inside the bucket the threshold falls in.  Coefficients equal to the
+// threshold are all kept, so slightly more than `keep` can survive when values tie.
+MI_DEV u32 mag2_bits(f32x2v v) { return __float_as_uint(v.x * v.x + v.y * v.y); }
+
+__global__ __launch_bounds__(256) void mag_hist_hi_kernel(const f32x2v* __restrict__ d, i64 n, u32* __restrict__ hist)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        atomicAdd(&hist[mag2_bits(d[i]) >> 16], 1u);
+}
+
+__global__ __launch_bounds__(256) void mag_hist_lo_kernel(const f32x2v* __restrict__ d, i64 n, u32 hi, u32* __restrict__ hist)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 b = mag2_bits(d[i]);
+        if ((b >> 16) == hi) atomicAdd(&hist[b & 0xffffu], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i64 n, u32 threshold)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (mag2_bits(d[i]) < threshold) d[i] = f32x2v{0.f, 0.f};
+}
+
+// Blocking: reads the two histograms back on the host.
+int spectrum_keep_top(void* data, size_t n, size_t keep, hipStream_t s)
+{
+    if (keep >= n) return MI_OK;
+    u32* d_hist = nullptr;
+    hipError_t e = hipMalloc((void**)&d_hist, 65536 * sizeof(u32));
+    if (e != hipSuccess) return hip_status(e, "spectrum histogram");
+    std::vector<u32> hist(65536);
+    const int grid = flat_grid((i64)n);
+    u32 threshold = 0;
+    // walks a histogram from the top bucket down; returns the bucket holding the `want`-th
+    // largest element and leaves in `want` its rank inside that bucket
+    auto find_bucket = [&](size_t& want) {
+        size_t above = 0;
+        for (int b = 65535; b >= 0; b--) {
+            if (above + hist[b] >= want) { want -= above; return (u32)b; }
+            above += hist[b];
+        }
+        want = 1;
+        return 0u;
+    };
+    size_t want = keep == 0 ? 1 : keep;
+    e = hipMemsetAsync(d_hist, 0, 65536 * sizeof(u32), s);
+    if (e == hipSuccess) {
+        mag_hist_hi_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, d_hist);
+        e = hipMemcpyAsync(hist.data(), d_hist, 65536 * sizeof(u32), hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        const u32 hi = find_bucket(want);
+        e = hipMemsetAsync(d_hist, 0, 65536 * sizeof(u32), s);
+        if (e == hipSuccess) {
+            mag_hist_lo_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, hi, d_hist);
+            e = hipMemcpyAsync(hist.data(), d_hist, 65536 * sizeof(u32), hipMemcpyDeviceToHost, s);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            const u32 lo = find_bucket(want);
+            threshold = (hi << 16) | lo;
+            if (keep == 0) threshold = 0xffffffffu;      // nothing survives
+            mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, threshold);
+            e = hipGetLastError();
+        }
+    }
+    (void)hipFree(d_hist);
+    return hip_status(e, "spectrum_keep_top");
 }
 
 }  // namespace mi

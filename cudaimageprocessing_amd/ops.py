@@ -297,6 +297,23 @@ def imageMedianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize=3
                                    width, height, int(kernalSize)))
 
 
+def compressImage(outputImage, inputImage, width, height, keep_fraction=0.10):
+    """compressImage (kernels/imageTools.h:17; undefined upstream): keep the largest DFT coefficients."""
+    check(lib().mi_compress_u8x4(_host_img(inputImage, width, height), _host_img(outputImage, width, height),
+                                 width, height, float(keep_fraction)))
+
+
+def spectrum_keep_top_(x, keep):
+    """Zero all but the `keep` largest-magnitude values of a complex64 device tensor, in place."""
+    check(lib().mi_spectrum_keep_top_dev(x.data_ptr(), x.numel(), int(keep), _stream()))
+    return x
+
+
+def test():
+    """bool test() (kernels/imageTools.h:19; undefined upstream): the library's self-test."""
+    return lib().mi_selftest() == _lib.MI_OK
+
+
 _OP_NAMES = {"gray": _lib.FILTER_GRAYSCALE, "grayscale": _lib.FILTER_GRAYSCALE, "sobel": _lib.FILTER_SOBEL,
              "gauss": _lib.FILTER_GAUSSIAN, "gaussian": _lib.FILTER_GAUSSIAN, "gauss_direct": _lib.FILTER_GAUSSIAN_DIRECT,
              "mean": _lib.FILTER_MEAN, "median": _lib.FILTER_MEDIAN}

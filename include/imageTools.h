@@ -22,8 +22,12 @@ void imageSobelEdgeWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, 
 void imageGaussianBlurWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height, int kernalSize, float sigma);
 void imageMeanBlurWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height);
 void imageFFTImageGenerate(uchar4* returnImage, uchar4* imageLoaded, int width, int height);
-// Declared but never defined upstream (kernels/imageTools.h:17); not defined here yet either.
+// Declared but never defined upstream (kernels/imageTools.h:17, call commented out at main.cpp:44).
+// Defined here as: keep the 10 % largest DFT coefficients of each channel (mi_compress_u8x4).
 void compressImage(uchar4* outputImage, uchar4* inputImage, int width, int height);
+// Declared but never defined upstream (kernels/imageTools.h:19): the library's self-test
+// (mi_selftest) -- true when every known-answer check passes on the current device.
+bool test();
 // Returns malloc()ed memory; the caller frees it (kernels/imageTools.cu:364, 501).
 float* generateGaussianKernal(int kernalSize, float sigma);
 // New: the median blur the reference's README advertises (kernalSize 3 or 5).

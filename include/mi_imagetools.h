@@ -44,6 +44,7 @@ extern "C" {
 #define MI_ERR_UNSUPPORTED (-3)   /* a shape this build has no kernel for */
 #define MI_ERR_OVERLAP (-4)       /* device-tier in/out buffers overlap */
 #define MI_ERR_IO (-5)            /* file could not be written */
+#define MI_ERR_SELFTEST (-6)      /* mi_selftest found a wrong result */
 
 #define MI_MAX_KERNEL_SIZE 31
 
@@ -202,6 +203,21 @@ int mi_host_release(void);
 /* imageFFTImageGenerate (imageTools.cu:633-791) without its debug means; cutoff is the
  * reference's hard-coded 10.0f (:716). */
 int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);
+/* compressImage (declared at kernels/imageTools.h:17 and commented out at main.cpp:44, never
+ * defined upstream; defined by this library on the round-trip scaffold of imageFFTImageGenerate):
+ * per colour channel, forward 2-D DFT, keep the ceil(keep_fraction * w * h) coefficients of
+ * largest magnitude (ties at the threshold all stay) and zero the rest, inverse DFT, /N, real
+ * part saturated to u8, alpha 255.  keep_fraction in (0, 1]; 1 reproduces the input. */
+#define MI_COMPRESS_DEFAULT_KEEP 0.10f
+int mi_compress_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float keep_fraction);
+/* The selection step of mi_compress_u8x4 on a device spectrum of n complex values, in place.
+ * Blocking (the threshold search reads two histograms back to the host). */
+int mi_spectrum_keep_top_dev(void *d_data, size_t n, size_t keep, void *stream);
+/* bool test() (declared at kernels/imageTools.h:19, never defined upstream): the library's
+ * self-test -- known-answer checks of every filter, the transforms and the host pipeline on
+ * the current device.  Returns MI_OK, or MI_ERR_SELFTEST with the first failure in
+ * mi_last_error(); every failure is also printed to stderr. */
+int mi_selftest(void);
 /* generateGaussianKernal (imageTools.cu:362-385): fills out[kernel_size^2] on the host. */
 int mi_gaussian_kernel(int kernel_size, float sigma, float *out);
 

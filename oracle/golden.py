@@ -269,3 +269,25 @@ def normalize_to_u8(img, mn=None, mx=None):
     out = np.empty(a.shape + (4,), np.uint8)
     lib().gold_normalize_to_u8(_p(a), _p(out), a.size, mn, mx)
     return out
+
+
+def compress_image(img, keep_fraction):
+    """compressImage (kernels/imageTools.h:17, main.cpp:44; declared, never defined upstream), as
+    this build defines it on imageFFTImageGenerate's round-trip scaffold (imageTools.cu:633-791):
+    per channel, forward DFT (double), keep the ceil(keep*N) coefficients of largest |X|^2 (ties
+    at the threshold all stay), inverse DFT, /N, real part saturated to u8 (gold_complex_to_u8).
+    numpy restatement: parity unpinned -- the reference holds no definition and no output."""
+    img = _img(img)
+    h, w = img.shape[:2]
+    n = h * w
+    keep = int(min(n, max(1, np.ceil(np.float32(keep_fraction).astype(np.float64) * n))))
+    planes = []
+    for c in range(3):
+        spec = np.fft.fft2(img[..., c].astype(np.float64))
+        mag2 = spec.real ** 2 + spec.imag ** 2
+        if keep < n:
+            thr = np.partition(mag2.ravel(), n - keep)[n - keep]
+            spec = np.where(mag2 >= thr, spec, 0.0)
+        back = np.fft.ifft2(spec)
+        planes.append(back.real.astype(np.float32).astype(np.complex64))
+    return complex_to_u8(planes[0], planes[1], planes[2])

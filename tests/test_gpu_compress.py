@@ -1,0 +1,80 @@
+"""GPU tests of compressImage (kernels/imageTools.h:17 -- declared, never defined upstream; this
+build's definition is in include/mi_imagetools.h), its selection step, and bool test()
+(kernels/imageTools.h:19, likewise).  Parity unpinned: the oracle is this build's own numpy
+restatement of the same definition."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from cudaimageprocessing_amd import _lib, ops, synth as S  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("n,keep", [(10007, 1000), (4096, 1), (65536 * 3, 70000), (33, 32)])
+def test_keep_top_selects_the_largest(dev, n, keep):
+    rng = np.random.default_rng(n + keep)
+    x = (rng.normal(0, 100, n) + 1j * rng.normal(0, 100, n)).astype(np.complex64)
+    x[::97] *= 1e-12                                                  # a spread of exponents
+    x[5] = 0
+    y = ops.spectrum_keep_top_(torch.from_numpy(x).to(dev), keep).cpu().numpy()
+    kept = y != 0
+    assert kept.sum() == keep                                         # random values: no ties
+    assert np.array_equal(y[kept], x[kept])
+    mag2 = x.real.astype(np.float64) ** 2 + x.imag.astype(np.float64) ** 2
+    assert mag2[kept].min() >= mag2[~kept].max() * (1 - 1e-6)
+
+
+def test_keep_top_edge_cases(dev):
+    x = torch.full((1000,), 3 + 4j, dtype=torch.complex64, device=dev)
+    assert torch.equal(ops.spectrum_keep_top_(x.clone(), 5), x)       # ties at the threshold all stay
+    assert torch.equal(ops.spectrum_keep_top_(x.clone(), 1000), x)
+    assert torch.equal(ops.spectrum_keep_top_(x.clone(), 5000), x)
+    assert int((ops.spectrum_keep_top_(x.clone(), 0) != 0).sum()) == 0
+    z = torch.zeros(64, dtype=torch.complex64, device=dev)
+    z[7] = 1
+    out = ops.spectrum_keep_top_(z.clone(), 1)
+    assert torch.equal(out, z)
+
+
+@pytest.mark.parametrize("w,h", [(128, 64), (90, 60), (64, 100)])
+@pytest.mark.parametrize("keep", [0.02, 0.10, 0.5])
+def test_compress_matches_oracle(dev, golden, w, h, keep):
+    img = S.pattern_image("natural", w, h, 11)
+    out = np.empty_like(img)
+    ops.compressImage(out, img, w, h, keep)
+    ref = golden.compress_image(img, keep)
+    # fp32 spectrum on the device, double in the oracle: a coefficient sitting at the threshold
+    # may fall on either side, so the images agree closely but not bit for bit
+    d = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 3 and d.mean() < 0.2
+    assert (out[..., 3] == 255).all()
+
+
+def test_compress_keep_all_and_quality_grows_with_keep(dev):
+    w, h = 96, 80
+    img = S.pattern_image("natural", w, h, 5)
+    out = np.empty_like(img)
+    ops.compressImage(out, img, w, h, 1.0)
+    assert np.abs(out[..., :3].astype(np.int16) - img[..., :3].astype(np.int16)).max() <= 1
+    err = []
+    for keep in (0.01, 0.05, 0.25, 0.75):
+        ops.compressImage(out, img, w, h, keep)
+        err.append(float(np.mean((out[..., :3].astype(np.float64) - img[..., :3]) ** 2)))
+    assert err[0] > err[1] > err[2] > err[3]
+    with pytest.raises(_lib.MiError):
+        ops.compressImage(out, img, w, h, 0.0)
+    with pytest.raises(_lib.MiError):
+        ops.compressImage(out, img, w, h, 1.5)
+
+
+def test_library_selftest(dev):
+    assert ops.test() is True

@@ -358,3 +358,21 @@ def test_minmax_normalize(golden):
     q = golden.normalize_to_u8(x)
     assert q[..., 0].tolist() == [[0, 63], [255, 127]] and (q[..., 3] == 255).all()
     assert (golden.normalize_to_u8(np.full((2, 2), 5.0, np.float32))[..., 0] == 0).all()
+
+
+def test_compress_restatement_known_answers(golden):
+    """compressImage as this build defines it (no reference definition exists): keep-all is the
+    identity, a constant image survives on its single non-zero coefficient, a pure cosine on two."""
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (12, 10, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    assert np.abs(golden.compress_image(img, 1.0).astype(int) - img).max() <= 1
+    flat = np.empty((8, 8, 4), np.uint8)
+    flat[...] = (10, 200, 77, 255)
+    assert np.abs(golden.compress_image(flat, 1 / 64).astype(int) - flat).max() <= 1
+    xx = np.arange(16)[None, :].repeat(16, 0)
+    wave = (128 + 100 * np.cos(2 * np.pi * 3 * xx / 16)).astype(np.uint8)
+    im = np.stack([wave, wave, wave, np.full_like(wave, 255)], -1)
+    out = golden.compress_image(im, 3 / 256)            # DC + the two cosine bins
+    assert np.abs(out.astype(int) - im).max() <= 2
+    assert np.abs(golden.compress_image(im, 1 / 256).astype(int)[..., 0] - 127).max() <= 2   # DC only

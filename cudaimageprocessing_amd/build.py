@@ -56,5 +56,24 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+DEMO_SRC = os.path.normpath(os.path.join(_PKG, "..", "demo", "imgtool.cpp"))
+DEMO_BIN = os.path.normpath(os.path.join(_PKG, "..", "demo", "imgtool"))
+
+
+def build_demo(force=False):
+    """demo/imgtool: the C++ demo program, linked against the in-tree library."""
+    if not os.path.exists(DEMO_SRC):
+        return None
+    lib = build()
+    if (not force and os.path.exists(DEMO_BIN) and os.path.getmtime(DEMO_BIN) > os.path.getmtime(DEMO_SRC)
+            and os.path.getmtime(DEMO_BIN) > os.path.getmtime(lib)):
+        return DEMO_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-x", "c++", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", DEMO_SRC, "-o", DEMO_BIN,
+                           "-L" + _PKG, "-lmi_imagetools", "-lz", "-Wl,-rpath,$ORIGIN/../cudaimageprocessing_amd"])
+    return DEMO_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_demo(force="--force" in sys.argv))

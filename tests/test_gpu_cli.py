@@ -1,0 +1,105 @@
+"""GPU tests of the two demo programs (counterparts of the reference's main.cpp:12-49):
+demo/imgtool (C++, written against include/imageTools.h) and `python -m cudaimageprocessing_amd.cli`."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from cudaimageprocessing_amd import _lib, cli, ops, synth as S  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IMGTOOL = os.path.join(ROOT, "demo", "imgtool")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    _lib.lib()
+    assert os.path.exists(IMGTOOL), "demo/imgtool is built by __graft_entry__.build()"
+    return torch.device("cuda:0")
+
+
+def read_png(path):
+    data = open(path, "rb").read()
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        tag, body = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            w, h = int.from_bytes(body[:4], "big"), int.from_bytes(body[4:8], "big")
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+    return raw[:, 1:].reshape(h, w, 4).copy()
+
+
+def run_tool(*args):
+    p = subprocess.run([IMGTOOL, *args], capture_output=True, text=True, timeout=100)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p.stdout
+
+
+def test_imgtool_selftest(dev):
+    assert "passed" in run_tool("--selftest")
+
+
+@pytest.mark.parametrize("flags", [[], ["--one-trip"]])
+def test_imgtool_filter_list(dev, tmp_path, flags):
+    w, h = 300, 200
+    img = S.pattern_image("natural", w, h, 21)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    ops.imageWriteWrapper(src, img, w, h)
+    spec = "gray,gauss:5:1.0,median:3,sobel,mean:5,median:5"
+    out = run_tool(src, dst, "--ops", spec, *flags)
+    assert f"{w} x {h}" in out
+    want = np.empty_like(img)
+    ops.run_ops(want, img, w, h, spec)
+    assert np.array_equal(read_png(dst), want)
+
+
+def test_imgtool_ppm_input_and_default_op(dev, tmp_path, golden):
+    w, h = 64, 48
+    img = S.pattern_image("natural", w, h, 2)
+    src, dst = str(tmp_path / "in.ppm"), str(tmp_path / "out.png")
+    with open(src, "wb") as f:
+        f.write(b"P6\n# made by the test\n%d %d\n255\n" % (w, h) + img[..., :3].tobytes())
+    run_tool(src, dst)                                    # default op: the FFT high-pass, like upstream's main.cpp
+    want = np.empty_like(img)
+    ops.imageFFTImageGenerate(want, img, w, h)
+    assert np.array_equal(read_png(dst), want)
+    ref, _ = golden.fft_highpass_image(img, 10.0)
+    assert np.abs(read_png(dst).astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    run_tool(src, dst, "--ops", "compress:0.25")
+    ops.compressImage(want, img, w, h, 0.25)
+    assert np.array_equal(read_png(dst), want)
+
+
+def test_imgtool_rejects_bad_input(dev, tmp_path):
+    bad = str(tmp_path / "x.bin")
+    open(bad, "wb").write(b"not an image")
+    p = subprocess.run([IMGTOOL, bad, str(tmp_path / "o.png")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "unknown image format" in p.stderr
+    p = subprocess.run([IMGTOOL, os.path.join(ROOT, "tests", "golden", "deer.jpeg"), str(tmp_path / "o.png")],
+                       capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "JPEG" in p.stderr
+
+
+def test_python_cli_on_the_sample_jpeg(dev, tmp_path, capsys):
+    Image = pytest.importorskip("PIL.Image")
+    src = os.path.join(ROOT, "tests", "golden", "deer.jpeg")
+    dst = str(tmp_path / "deer_edges.png")
+    assert cli.main([src, dst, "--ops", "gray,gauss:5:1.0,sobel", "--one-trip"]) == 0
+    rgba = np.ascontiguousarray(np.asarray(Image.open(src).convert("RGBA")))
+    h, w = rgba.shape[:2]
+    want = np.empty_like(rgba)
+    ops.run_ops(want, rgba, w, h, "gray,gauss:5:1.0,sobel")
+    assert np.array_equal(read_png(dst), want)
+    assert cli.main(["--selftest"]) == 0
+    assert "passed" in capsys.readouterr().out

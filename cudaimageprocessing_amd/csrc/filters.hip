@@ -839,7 +839,7 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     // early stages; shrink them only to fill the machine
     int rpb = env_int("MI_CHAIN_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
-        rpb = 60;
+        rpb = 30;
         while (rpb > 8 && (i64)batch * g.strips * ((H + rpb - 1) / rpb) < 8192) rpb >>= 1;
     }
     rpb = std::max(1, std::min(rpb, (int)((1LL << 28) / W)));

@@ -14,7 +14,7 @@ from cudaimageprocessing_amd import ops  # noqa: E402
 
 W, H = 3840, 2160
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-ROUNDS = 7
+ROUNDS = 3
 
 frames = ops.synth(2, W, H, batch=B)
 out = torch.empty_like(frames)
@@ -27,6 +27,7 @@ FILTERS = {
     "median3": lambda: ops.median_blur(frames, 3, out),
     "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),
 }
+CHAIN = {"chain": lambda: ops.fused_chain(frames, 1.0, out)}
 EXTRA = {
     "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
     "gauss9": lambda: ops.gaussian_blur(frames, 9, 2.0, out),
@@ -35,7 +36,7 @@ EXTRA = {
 }
 
 
-def timed(fn, reps=3):
+def timed(fn, reps=40):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
@@ -66,9 +67,12 @@ def sweep(filters, configs):
 if __name__ == "__main__":
     for fn in list(FILTERS.values()) + list(EXTRA.values()):
         fn()
+    timed(CHAIN["chain"], 400)     # spin the clocks up: the first ~50 ms of work run 20 % slower
     torch.cuda.synchronize()
     mode = sys.argv[2] if len(sys.argv) > 2 else "main"
-    if mode == "main":
+    if mode == "chain":
+        sweep(CHAIN, [dict(MI_CHAIN_ROWS_PER_BAND=r) for r in (16, 20, 24, 27, 30, 32, 36, 40, 45, 48, 54, 60, 72, 90, 108)])
+    elif mode == "main":
         sweep(FILTERS, [dict(MI_ROWS_PER_BAND=r) for r in (4, 6, 8, 12, 16, 24, 32)])
     else:
         sweep(EXTRA, [dict(MI_ROWS_PER_BAND=r) for r in (8, 16, 32, 64)])

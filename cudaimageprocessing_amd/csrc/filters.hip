@@ -4,6 +4,8 @@
 // Semantics follow kernels/imageTools.cu of the reference (citations at each kernel); the
 // execution scheme ("wave march", see common.h) is this library's own.
 // Build with -ffp-contract=off: every fused multiply-add is spelled out.
+#include <array>
+
 #include "common.h"
 #include "internal.h"
 #include "median5_network.h"
@@ -432,6 +434,99 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
     }
 }
 
+// ============================================================================ mean, 5x5 .. 15x15
+// imageMeanBlur, imageTools.cu:313-340, for kernel sizes 5..15 (the reference's wrapper
+// hard-codes 3, :806; its kernel takes any size): integer sums of the k*k flat taps per channel,
+// integer division by k*k, alpha 255.  Separable and exact: a row pass of sliding K-sums on
+// packed u16 pairs ((R,B) and (G,A) of a pixel; a row sum is at most 15*255), a running column
+// sum over the K most recent row sums (at most 225*255 = 57375, still 16 bits), and the division
+// as (s * ceil(2^24 / k^2)) >> 24, which is exact for every reachable s (checked at launch).
+template <int R, int POL>
+__global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ in,
+                                                       u32* __restrict__ out, const Geo g,
+                                                       const u32 magic)
+{
+    constexpr int K = 2 * R + 1;
+    constexpr int HOPS = (R + 3) / 4;
+    MI_MARCH_PROLOGUE();
+
+    struct RowIn { u32x4 p, h1, h2; };
+    auto load_row = [&](int row) {
+        RowIn r;
+        r.p = io.load(row);
+        r.h1 = io.load_halo(row, 1);
+        if (HOPS > 1) r.h2 = io.load_halo(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
+        return r;
+    };
+    // h[2k] = (R,B) sums, h[2k+1] = (G,A) sums over columns k-R .. k+R, for the lane's pixel k
+    auto hrow = [&](const RowIn& r, u32 (&h)[8]) {
+        u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
+        const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+        const u32 e1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        const u32 e2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[8 + k] = p[k];
+            col[4 + k] = from_left(p[k], e1[k]);
+            col[12 + k] = from_right(p[k], e1[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[k] = from_left(col[4 + k], e2[k]);
+            col[16 + k] = from_right(col[12 + k], e2[k]);
+        }
+        u32 lo[4 + 2 * R], hi[4 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * R; i++) unpack_px(col[8 - R + i], lo[i], hi[i]);
+        u32 sl = lo[0], sh = hi[0];
+#pragma unroll
+        for (int i = 1; i < K; i++) { sl = pk_add(sl, lo[i]); sh = pk_add(sh, hi[i]); }
+        h[0] = sl; h[1] = sh;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            sl = pk_add(pk_sub(sl, lo[k - 1]), lo[k + K - 1]);
+            sh = pk_add(pk_sub(sh, hi[k - 1]), hi[k + K - 1]);
+            h[2 * k] = sl; h[2 * k + 1] = sh;
+        }
+    };
+
+    u32 win[K][8];
+    u32 cs[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) {
+        hrow(load_row(mch.row(i - R)), win[i]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[i][e]);
+    }
+    RowIn nxt = load_row(mch.row(R));
+    for (int base = 0; base < mch.n; base += K) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
+            // rows y-R+t live in slot (s+t)%K; the newest one, y+R, replaces the row dropped last step
+            hrow(nxt, win[(K - 1 + s) % K]);
+            nxt = load_row(mch.row(i + R + 1));
+#pragma unroll
+            for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[(K - 1 + s) % K][e]);
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 qr = ((cs[2 * k] & 0xFFFFu) * magic) >> 24;
+                const u32 qb = ((cs[2 * k] >> 16) * magic) >> 24;
+                const u32 qg = ((cs[2 * k + 1] & 0xFFFFu) * magic) >> 24;
+                o[k] = (qr | (qg << 8) | (qb << 16) | 0xFF000000u) & xm[k] & rowm;
+            }
+            io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+#pragma unroll
+            for (int e = 0; e < 8; e++) cs[e] = pk_sub(cs[e], win[s % K][e]);   // drop row y-R
+            }
+        }
+    }
+}
+
 // ============================================================================ fused chain
 // gray -> Gaussian 5x5 -> median 3x3 -> Sobel (BASELINE.json config 2) in one pass: 8 bytes of
 // HBM traffic per pixel instead of 32.  After the grayscale stage the three colour channels are
@@ -728,11 +823,13 @@ __global__ __launch_bounds__(256) void median5_kernel(const u32* __restrict__ in
 }
 
 // ============================================================================ utility kernels
+// One 16-byte non-temporal load + store per lane, the grid covers the buffer once (the streaming
+// shape that measured fastest, see gray_kernel).
 __global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ src,
                                                      u32x4* __restrict__ dst, i64 n16)
 {
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 __global__ __launch_bounds__(256) void copy1_kernel(const unsigned char* __restrict__ src,
@@ -768,9 +865,12 @@ int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MI_OK;
     if ((((uintptr_t)src | (uintptr_t)dst | bytes) & 15) == 0) {
-        const i64 n16 = (i64)(bytes >> 4);
-        const int grid = (int)std::min<i64>((n16 + 255) / 256, grid_cap());
-        copy16_kernel<<<grid, 256, 0, s>>>((const u32x4*)src, (u32x4*)dst, n16);
+        // at most 2^31-1 blocks of 4 KiB per launch
+        const i64 per_launch = (i64)0x7fffffff * 256;
+        for (i64 done = 0, n16 = (i64)(bytes >> 4); done < n16; done += per_launch) {
+            const i64 n = std::min(per_launch, n16 - done);
+            copy16_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>((const u32x4*)src + done, (u32x4*)dst + done, n);
+        }
     } else {
         const int grid = (int)std::min<i64>(((i64)bytes + 255) / 256, grid_cap());
         copy1_kernel<<<grid, 256, 0, s>>>((const unsigned char*)src, (unsigned char*)dst, (i64)bytes);
@@ -819,6 +919,32 @@ static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u3
                              const Geo& g, const GaussW& gw)
 {
 #define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+    MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+}
+
+// magic with (s * magic) >> 24 == s / k^2 for every s <= 255 k^2 and s * magic < 2^32, verified
+// exhaustively once per process (0 if there is none).
+static u32 mean_magic(int k)
+{
+    static const std::array<u32, 16> table = [] {
+        std::array<u32, 16> t{};
+        for (int ks = 5; ks <= 15; ks += 2) {
+            const u32 d = (u32)(ks * ks), m = ((1u << 24) + d - 1) / d;
+            bool ok = true;
+            for (u32 sum = 0; sum <= 255u * d && ok; sum++)
+                ok = (uint64_t)sum * m <= 0xFFFFFFFFull && (u32)(((uint64_t)sum * m) >> 24) == sum / d;
+            t[ks] = ok ? m : 0u;
+        }
+        return t;
+    }();
+    return (k >= 0 && k < 16) ? table[k] : 0u;
+}
+
+template <int R>
+static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic)
+{
+#define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, magic)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }
@@ -899,7 +1025,7 @@ int launch_filter(const FilterArgs& a)
 
     // generic one-thread-per-pixel kernels
     const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT;
-    const bool mean_generic = a.filter == MI_FILTER_MEAN && a.ksize != 3;
+    const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15);
     if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {
@@ -934,7 +1060,7 @@ int launch_filter(const FilterArgs& a)
     // A taller band amortises the row pass of a wide Gaussian over more output rows.
     int rpb = env_int("MI_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
-        const int r = a.filter == MI_FILTER_GAUSSIAN ? a.ksize / 2 : 1;
+        const int r = (a.filter == MI_FILTER_GAUSSIAN || a.filter == MI_FILTER_MEAN) ? a.ksize / 2 : 1;
         rpb = r == 1 ? 6 : std::min(10 * r, 64);
         if (median5) rpb = 32;   // VALU-bound: amortise the 4 extra rows of a band
         // wide Gaussians: 2R extra row passes per band, two waves per SIMD -> taller bands, fewer waves
@@ -962,11 +1088,23 @@ int launch_filter(const FilterArgs& a)
     }
         break;
     case MI_FILTER_MEAN:
-    {
+        if (a.ksize == 3) {
 #define MI_L(P) mean3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
-        MI_POLICY_CASES(pol, MI_L)
+            MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
-    }
+        } else {
+            const u32 magic = mean_magic(a.ksize);
+            if (!magic) return fail(MI_ERR_UNSUPPORTED, "no exact reciprocal for mean kernel size %d", a.ksize);
+            switch (a.ksize / 2) {
+            case 2: launch_mean_sep<2>(pol, grid, a.stream, in, out, g, magic); break;
+            case 3: launch_mean_sep<3>(pol, grid, a.stream, in, out, g, magic); break;
+            case 4: launch_mean_sep<4>(pol, grid, a.stream, in, out, g, magic); break;
+            case 5: launch_mean_sep<5>(pol, grid, a.stream, in, out, g, magic); break;
+            case 6: launch_mean_sep<6>(pol, grid, a.stream, in, out, g, magic); break;
+            case 7: launch_mean_sep<7>(pol, grid, a.stream, in, out, g, magic); break;
+            default: return fail(MI_ERR_BAD_KERNEL_SIZE, "separable mean supports kernel sizes 5..15");
+            }
+        }
         break;
     case MI_FILTER_MEDIAN:
     {

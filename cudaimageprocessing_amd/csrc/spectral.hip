@@ -112,14 +112,26 @@ __global__ void minmax_init_kernel(int* keys)
     keys[1] = (int)0x80000000;
 }
 
+// Each lane reads 16-byte groups (the ragged head and tail of an unaligned buffer go to lane 0
+// of block 0), wave reduction by DPP-free shuffles, one pair of atomics per block.
 __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ img, i64 n,
                                                      int* __restrict__ keys)
 {
     float mn = __builtin_inff(), mx = -__builtin_inff();
+    auto take = [&](float v) { if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); } };
+    // elements before the first 16-byte boundary
+    i64 head = (i64)((16 - ((uintptr_t)img & 15)) & 15) / 4;
+    if (head > n) head = n;
+    const i64 groups = (n - head) / 4;
+    const f32x4v* g4 = reinterpret_cast<const f32x4v*>(img + head);
     const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = img[i];
-        if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += stride) {
+        const f32x4v v = g4[i];
+        take(v.x); take(v.y); take(v.z); take(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (i64 i = 0; i < head; i++) take(img[i]);
+        for (i64 i = head + 4 * groups; i < n; i++) take(img[i]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -198,7 +210,8 @@ int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s)
 int launch_minmax(const void* img, size_t n, void* minmax, hipStream_t s)
 {
     minmax_init_kernel<<<1, 1, 0, s>>>((int*)minmax);
-    minmax_kernel<<<flat_grid((i64)n, 8), 256, 0, s>>>((const float*)img, (i64)n, (int*)minmax);
+    // few blocks: every block ends with two atomics on the same two words
+    minmax_kernel<<<std::min(flat_grid((i64)n, 16), 512), 256, 0, s>>>((const float*)img, (i64)n, (int*)minmax);
     minmax_final_kernel<<<1, 1, 0, s>>>((const int*)minmax, (float*)minmax);
     return hip_status(hipGetLastError(), "minmax launch");
 }

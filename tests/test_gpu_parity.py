@@ -98,11 +98,13 @@ def test_mean3(dev, golden, w, h, kind):
     assert np.array_equal(host(ops.mean_blur(to_dev(img, dev), 3)), golden.meanblur(img, 3))
 
 
-@pytest.mark.parametrize("k", [1, 5, 7, 11])
+@pytest.mark.parametrize("k", [1, 5, 7, 9, 11, 13, 15, 17, 31])
 def test_mean_other_sizes(dev, golden, k):
-    for (w, h) in ((67, 45), (256, 16), (5, 7)):
+    for (w, h) in ((67, 45), (256, 16), (5, 7), (300, 70), (512, 33)):
         img = S.synth_image(k, w, h)
         assert np.array_equal(host(ops.mean_blur(to_dev(img, dev), k)), golden.meanblur(img, k))
+    white = np.full((40, 300, 4), 255, np.uint8)       # the largest sums the packed 16-bit lanes must hold
+    assert np.array_equal(host(ops.mean_blur(to_dev(white, dev), k)), golden.meanblur(white, k))
 
 
 # ------------------------------------------------------------------ median
@@ -173,6 +175,7 @@ STRIP_FILTERS = [
     (_lib.FILTER_GRAYSCALE, 0, 0.0), (_lib.FILTER_SOBEL, 3, 0.0), (_lib.FILTER_MEAN, 3, 0.0),
     (_lib.FILTER_MEDIAN, 3, 0.0), (_lib.FILTER_MEDIAN, 5, 0.0), (_lib.FILTER_GAUSSIAN, 5, 1.0),
     (_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_GAUSSIAN_DIRECT, 5, 1.0), (_lib.FILTER_MEAN, 7, 0.0),
+    (_lib.FILTER_MEAN, 15, 0.0), (_lib.FILTER_MEAN, 17, 0.0),
 ]
 
 

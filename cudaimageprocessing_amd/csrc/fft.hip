@@ -146,10 +146,27 @@ MI_DEV LineAddr line_addr(const FftGeo& g, int L)
 
 MI_DEV int lds_pad(int i) { return i + (i >> 4); }   // one spare slot per 16: breaks the 128-byte stride
 
+// Stage plan of an N-point line: radix-16 stages, then one radix-2/4/8 stage when log2 N is not a
+// multiple of 4.  The twiddles of stage s (all but the first stage have some) sit in LDS as a
+// table [(q-1) * NS + ktw] = exp(-2 pi i q ktw / (NS R)), q = 1..R-1, ktw = 0..NS-1, filled once
+// per block: inside the line loop the only vector-memory traffic is then the lines themselves, so
+// the in-order vmcnt counter never makes a stage wait for the prefetch of the next line.
+template <int N>
+struct Plan {
+    static constexpr int L = __builtin_ctz(N);
+    static constexpr int A = L / 4;                  // radix-16 stages
+    static constexpr int REM = 1 << (L % 4);         // trailing radix (1 = none)
+    static constexpr int n_stages = A + (REM > 1 ? 1 : 0);
+    static constexpr int radix(int s) { return s < A ? 16 : REM; }
+    static constexpr int ns(int s) { int p = 1; for (int i = 0; i < s; i++) p *= radix(i); return p; }
+    static constexpr int tw_off(int s) { int o = 0; for (int i = 1; i < s; i++) o += (radix(i) - 1) * ns(i); return o; }
+    static constexpr int tw_total = tw_off(n_stages);
+};
+
 // One Stockham stage of radix R over this lane's 16 points (N/16 lanes per line).
-// NS = product of the radices of the earlier stages.
+// NS = product of the radices of the earlier stages; tws = this stage's twiddle table.
 template <int N, int R, int NS, bool LAST>
-MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, int t)
+MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, const c2* __restrict__ tws, int t)
 {
     constexpr int T = N / 16, G = 16 / R;
 #pragma unroll
@@ -160,9 +177,8 @@ MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, int t)
 #pragma unroll
         for (int q = 0; q < R; q++) x[q] = v[m + q * G];
         if (NS > 1) {
-            constexpr int step = TW_N / (NS * R);
 #pragma unroll
-            for (int q = 1; q < R; q++) x[q] = cmul(x[q], g_twiddle[q * ktw * step]);
+            for (int q = 1; q < R; q++) x[q] = cmul(x[q], tws[(q - 1) * NS + ktw]);
         }
         dft<R>(x);
         if (LAST) {
@@ -182,34 +198,28 @@ MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, int t)
     }
 }
 
-template <int N>
-MI_DEV void fft_line(c2 (&v)[16], c2* __restrict__ line, int t)
+template <int N, int S = 0>
+MI_DEV void fft_line(c2 (&v)[16], c2* __restrict__ line, const c2* __restrict__ tw, int t)
 {
-    constexpr int L = __builtin_ctz(N);
-    constexpr int A = L / 4;                  // radix-16 stages
-    constexpr int REM = 1 << (L % 4);         // trailing radix (1 = none)
-    if constexpr (A == 1 && REM == 1) {
-        fft_stage<N, 16, 1, true>(v, line, t);
-    } else if constexpr (A == 1) {
-        fft_stage<N, 16, 1, false>(v, line, t);
-        fft_stage<N, REM, 16, true>(v, line, t);
-    } else if constexpr (A == 2 && REM == 1) {
-        fft_stage<N, 16, 1, false>(v, line, t);
-        fft_stage<N, 16, 16, true>(v, line, t);
-    } else if constexpr (A == 2) {
-        fft_stage<N, 16, 1, false>(v, line, t);
-        fft_stage<N, 16, 16, false>(v, line, t);
-        fft_stage<N, REM, 256, true>(v, line, t);
-    } else if constexpr (A == 3 && REM == 1) {
-        fft_stage<N, 16, 1, false>(v, line, t);
-        fft_stage<N, 16, 16, false>(v, line, t);
-        fft_stage<N, 16, 256, true>(v, line, t);
-    } else {
-        static_assert(A == 3 && REM == 2, "line length out of range");
-        fft_stage<N, 16, 1, false>(v, line, t);
-        fft_stage<N, 16, 16, false>(v, line, t);
-        fft_stage<N, 16, 256, false>(v, line, t);
-        fft_stage<N, 2, 4096, true>(v, line, t);
+    using P = Plan<N>;
+    if constexpr (S < P::n_stages) {
+        fft_stage<N, P::radix(S), P::ns(S), S == P::n_stages - 1>(v, line, tw + P::tw_off(S), t);
+        fft_line<N, S + 1>(v, line, tw, t);
+    }
+}
+
+// Fills the block's twiddle tables from the device table (all threads; caller synchronises).
+template <int N, int S = 1>
+MI_DEV void fill_twiddles(c2* __restrict__ tw, int tid, int nthreads)
+{
+    using P = Plan<N>;
+    if constexpr (S < P::n_stages) {
+        constexpr int R = P::radix(S), NS = P::ns(S), step = TW_N / (NS * R);
+        for (int idx = tid; idx < (R - 1) * NS; idx += nthreads) {
+            const int q = idx / NS + 1, k = idx % NS;
+            tw[P::tw_off(S) + idx] = g_twiddle[q * k * step];
+        }
+        fill_twiddles<N, S + 1>(tw, tid, nthreads);
     }
 }
 
@@ -237,6 +247,9 @@ void fft_lines_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Fft
     const int lin = COL ? tid % LPB : tid / T;
     const int t = COL ? tid / LPB : tid % T;
     c2* line = lds + lin * (N + N / 16);
+    c2* tw = lds + LPB * (N + N / 16);
+    fill_twiddles<N>(tw, tid, T * LPB);
+    __syncthreads();
     const int step = (int)gridDim.x * LPB;
     const int is = COL ? g.in_elem_stride : 1, os = COL ? g.out_elem_stride : 1;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)bytes, 0x00020000);
@@ -270,7 +283,7 @@ void fft_lines_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Fft
         }
         const LineAddr nx = line_addr(g, B + step + lin);
         if (PREFETCH && B + step < g.total_lines) load16(in_off(nx), nxt);
-        fft_line<N>(v, line, t);
+        fft_line<N>(v, line, tw, t);
         const u32 ooff = cur.active ? (u32)((cur.out + (i64)t * os) * 8) : 0x80000000u;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -338,10 +351,11 @@ template <int N, int LPB, bool COL, bool TW, bool PREFETCH>
 static int launch_lines_pf(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     constexpr int threads = (N / 16) * LPB;
-    constexpr size_t lds = (size_t)LPB * (N + N / 16) * sizeof(c2);
+    constexpr size_t lds = ((size_t)LPB * (N + N / 16) + Plan<N>::tw_total) * sizeof(c2);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     static int blocks_per_cu = 1;
+    static_assert(lds <= 160 * 1024, "a block's lines and twiddle tables must fit the CU's LDS");
     std::call_once(once, [] {
         if (lds > 64 * 1024)
             attr_err = hipFuncSetAttribute((const void*)fft_lines_kernel<N, LPB, COL, TW, PREFETCH>,
@@ -407,8 +421,8 @@ static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, u32 bytes,
     case 512: return launch_lines<512, COL ? 32 : 8, COL>(in, out, g, bytes, s);
     case 1024: return launch_lines<1024, COL ? 16 : 4, COL>(in, out, g, bytes, s);
     case 2048: return launch_lines<2048, COL ? 8 : 2, COL>(in, out, g, bytes, s);
-    case 4096: return launch_lines<4096, COL ? 4 : 1, COL>(in, out, g, bytes, s);
-    case 8192: return launch_lines<8192, COL ? 2 : 1, COL>(in, out, g, bytes, s);
+    case 4096: return launch_lines<4096, COL ? 2 : 1, COL>(in, out, g, bytes, s);   // 2 lines + 32 KiB of twiddles
+    case 8192: return launch_lines<8192, 1, COL>(in, out, g, bytes, s);              // 1 line + 64 KiB of twiddles
     default: return fail(MI_ERR_UNSUPPORTED, "fft line length %d", n);
     }
 }

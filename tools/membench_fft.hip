@@ -1,0 +1,88 @@
+// membench_fft.hip -- what the memory system delivers for the access patterns of the FFT passes,
+// without any arithmetic: every block copies "lines" the way fft_lines_kernel reads and writes them.
+//   row pattern   : a line is 32 KiB contiguous; lane t moves points t + 256 k, k = 0..15
+//   column pattern: 64 adjacent columns x 64 points, point stride 2 MiB (row stride 32 KiB x 64)
+// each with 8-byte or 16-byte accesses per lane, persistent (3 blocks per CU, register prefetch of
+// the next line) or one block per line.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/membench_fft tools/membench_fft.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef long long i64;
+
+// V = floats per access (2: b64, 4: b128).  A line = 4096 points of 8 bytes.
+template <int V, bool COL, bool PERSIST>
+__global__ __launch_bounds__(256) void lines_k(const float* __restrict__ in, float* __restrict__ out, int total_lines)
+{
+    typedef float vec __attribute__((ext_vector_type(V)));
+    constexpr int PTS = 16 * 2 / V;          // accesses per lane: 16 (b64) or 8 (b128)
+    const int t = threadIdx.x;
+    const int step = PERSIST ? gridDim.x : total_lines;
+    vec cur[PTS], nxt[PTS];
+    auto addr = [&](int line, int k) -> i64 {      // in floats
+        if (!COL) return (i64)line * 8192 + ((i64)t + 256 * k) * V;
+        // column pattern: "line" = block of 64 columns x 64 rows-with-stride; 4096 points per block
+        // line -> (plane-local) column group cg = line % 64, row group rg = line / 64
+        const i64 plane = line / 4096, l = line % 4096;
+        const i64 cg = l % 64, rg = l / 64;              // 64 column groups x 64 row residues per plane
+        // lanes: 64/ (V/2) lanes cover 64 columns (8 B each) => 512 B runs
+        constexpr int LPR = 64 * 2 / V;              // lanes per 512-byte run
+        const int row_in_blk = (t / LPR) + (256 / LPR) * k;          // 0..63
+        const i64 row = plane * 4096 + rg + 64 * (i64)row_in_blk;     // stride 64 rows
+        return (row * 4096 + cg * 64) * 2 + (t % LPR) * V;
+    };
+    int line = blockIdx.x;
+    if (line >= total_lines) return;
+#pragma unroll
+    for (int k = 0; k < PTS; k++) nxt[k] = *(const vec*)(in + addr(line, k));
+    for (; line < total_lines; line += step) {
+#pragma unroll
+        for (int k = 0; k < PTS; k++) cur[k] = nxt[k];
+        if (line + step < total_lines) {
+#pragma unroll
+            for (int k = 0; k < PTS; k++) nxt[k] = *(const vec*)(in + addr(line + step, k));
+        }
+#pragma unroll
+        for (int k = 0; k < PTS; k++) *(vec*)(out + addr(line, k)) = cur[k] * 2.0f;
+    }
+}
+
+template <int V, bool COL, bool PERSIST>
+void run(const char* name, const float* in, float* out, int total_lines, int grid)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int g = PERSIST ? grid : total_lines;
+    for (int i = 0; i < 3; i++) lines_k<V, COL, PERSIST><<<g, 256>>>(in, out, total_lines);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) lines_k<V, COL, PERSIST><<<g, 256>>>(in, out, total_lines);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-44s grid %6d  %.3f ms  %.0f GB/s\n", name, g, ms, (double)total_lines * 65536.0 / ms / 1e6);
+}
+
+int main()
+{
+    const int planes = 8;                       // 8 x 128 MiB in + out
+    const int total_lines = planes * 4096;
+    float *in, *out;
+    hipMalloc(&in, (size_t)total_lines * 32768);
+    hipMalloc(&out, (size_t)total_lines * 32768);
+    hipMemset(in, 0, (size_t)total_lines * 32768);
+    for (int grid : {512, 768, 1024, 2048}) {
+        run<2, false, true>("row b64 persistent", in, out, total_lines, grid);
+        run<4, false, true>("row b128 persistent", in, out, total_lines, grid);
+        run<2, true, true>("col b64 persistent", in, out, total_lines, grid);
+        run<4, true, true>("col b128 (1 KiB runs of 2 lanes/col) persistent", in, out, total_lines, grid);
+    }
+    run<2, false, false>("row b64 one block per line", in, out, total_lines, 0);
+    run<4, false, false>("row b128 one block per line", in, out, total_lines, 0);
+    run<2, true, false>("col b64 one block per line", in, out, total_lines, 0);
+    return 0;
+}

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmi_imagetools.so")
+# MI_IMAGETOOLS_LIB points the binding at another build of the library (kernel experiments)
+LIB_PATH = os.environ.get("MI_IMAGETOOLS_LIB") or os.path.join(_PKG, "libmi_imagetools.so")
 
 MI_OK = 0
 GAUSS_SEPARABLE, GAUSS_DIRECT = 0, 1

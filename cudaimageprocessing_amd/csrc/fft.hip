@@ -125,6 +125,7 @@ struct FftGeo {
     i64 in_group_stride, out_group_stride;
     int in_elem_stride, out_elem_stride;   // a line spans < 2^31 elements
     int tw_step;
+    int tw_uniform;        // all lines of a block iteration share their group index (inner >= lines per block)
     int inverse;
 };
 
@@ -264,35 +265,77 @@ void fft_lines_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Fft
         }
     };
 
-    int B = (int)blockIdx.x * LPB;                 // first line of this block's current group
-    LineAddr cur = line_addr(g, B + lin);
-    c2 nxt[16];
-    if (PREFETCH) load16(in_off(cur), nxt);
+    // Inter-pass twiddles of a split column transform: output kk of a line of group gi is
+    // multiplied by exp(-2 pi i gi kk tw_step / 8192).  When all lines of a block iteration share
+    // gi (cols >= LPB: the usual case) the N factors go through a double-buffered LDS table that
+    // lanes tid < N fill one iteration ahead -- their single load is issued before the prefetch
+    // of that iteration's lines, so nothing in the loop waits for anything younger than itself.
+    c2* twg = tw + Plan<N>::tw_total;                // 2 * N entries (TW kernels only)
+    // the prefetching variant is only launched for the shared-group case (launch_lines_tw)
+    const bool tw_shared = TW && (PREFETCH || g.tw_uniform);
+    auto tw_fetch = [&](const LineAddr& a) {
+        c2 w{1.f, 0.f};
+        if (TW && tw_shared && tid < N && a.active) w = g_twiddle[(a.g * tid * g.tw_step) & (TW_N - 1)];
+        return w;
+    };
 
-    for (; B < g.total_lines && B >= 0; B += step) {   // block-uniform trip count: barriers are safe
-        c2 v[16];
-        if (PREFETCH) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = nxt[k];
-        } else {
-            load16(in_off(cur), v);
-        }
+    // transform the 16 points in v (loaded from line `a`) and store them; `par` = table parity
+    auto process = [&](c2 (&v)[16], const LineAddr& a, c2 wnext, int par) {
         if (g.inverse) {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k].y = -v[k].y;
         }
-        const LineAddr nx = line_addr(g, B + step + lin);
-        if (PREFETCH && B + step < g.total_lines) load16(in_off(nx), nxt);
+        if (TW && tw_shared && tid < N) twg[par * N + tid] = wnext;
+        if (TW && Plan<N>::n_stages == 1) __syncthreads();     // otherwise the stage barriers order it
         fft_line<N>(v, line, tw, t);
-        const u32 ooff = cur.active ? (u32)((cur.out + (i64)t * os) * 8) : 0x80000000u;
+        const u32 ooff = a.active ? (u32)((a.out + (i64)t * os) * 8) : 0x80000000u;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             c2 r = v[k];
-            if (TW) r = cmul(r, g_twiddle[(cur.g * (t + T * k) * g.tw_step) & (TW_N - 1)]);
+            if (TW) r = cmul(r, tw_shared ? twg[par * N + t + T * k] : g_twiddle[(a.g * (t + T * k) * g.tw_step) & (TW_N - 1)]);
             if (g.inverse) r.y = -r.y;
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{r.x, r.y}), rout, ooff, (T * k) * os * 8, 0);
         }
-        cur = nx;
+    };
+
+    int B = (int)blockIdx.x * LPB;                 // first line of this block's current group
+    if (B >= g.total_lines) return;
+    if constexpr (PREFETCH) {
+        // Two register sets used alternately: while one line is transformed in place in `va`, the
+        // next one arrives in `vb`, and vice versa -- no copy ever reads a register that a load in
+        // flight is still to write (a copy would make the wave wait for its own prefetch).
+        // All trip counts are block-uniform, so the barriers inside are safe.
+        c2 va[16], vb[16];
+        LineAddr a0 = line_addr(g, B + lin);
+        c2 w0 = tw_fetch(a0);
+        load16(in_off(a0), va);
+        int par = 0;
+        while (true) {
+            const bool more1 = B + step < g.total_lines && B + step > 0;
+            const LineAddr a1 = line_addr(g, B + step + lin);
+            const c2 w1 = tw_fetch(a1);
+            if (more1) load16(in_off(a1), vb);
+            process(va, a0, w0, par);
+            if (!more1) break;
+            B += step;
+            const bool more2 = B + step < g.total_lines && B + step > 0;
+            const LineAddr a2 = line_addr(g, B + step + lin);
+            w0 = tw_fetch(a2);
+            if (more2) load16(in_off(a2), va);
+            process(vb, a1, w1, par ^ 1);
+            if (!more2) break;
+            B += step;
+            a0 = a2;
+        }
+    } else {
+        int par = 0;
+        for (; B < g.total_lines && B >= 0; B += step, par ^= 1) {
+            const LineAddr cur = line_addr(g, B + lin);
+            c2 v[16];
+            const c2 w = tw_fetch(cur);
+            load16(in_off(cur), v);
+            process(v, cur, w, par);
+        }
     }
 }
 
@@ -351,7 +394,7 @@ template <int N, int LPB, bool COL, bool TW, bool PREFETCH>
 static int launch_lines_pf(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     constexpr int threads = (N / 16) * LPB;
-    constexpr size_t lds = ((size_t)LPB * (N + N / 16) + Plan<N>::tw_total) * sizeof(c2);
+    constexpr size_t lds = ((size_t)LPB * (N + N / 16) + Plan<N>::tw_total + (TW ? 2 * N : 0)) * sizeof(c2);
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     static int blocks_per_cu = 1;
@@ -380,7 +423,7 @@ static int launch_lines_tw(const c2* in, c2* out, const FftGeo& g, u32 bytes, hi
 {
     // 1024-lane blocks have 128 registers per lane: no room to hold the next group's points
     if constexpr ((N / 16) * LPB <= 512) {
-        if (env_int("MI_FFT_PREFETCH", 1)) return launch_lines_pf<N, LPB, COL, TW, true>(in, out, g, bytes, s);
+        if (env_int("MI_FFT_PREFETCH", 1) && (!TW || g.tw_uniform)) return launch_lines_pf<N, LPB, COL, TW, true>(in, out, g, bytes, s);
     }
     return launch_lines_pf<N, LPB, COL, TW, false>(in, out, g, bytes, s);
 }
@@ -455,6 +498,7 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
         g.inverse = dir > 0;
         g.plane_stride = plane;
         g.tw_step = 0;
+        g.tw_uniform = 0;
         FftGeo row = g;
         row.inner_log2 = 0; row.groups_log2 = __builtin_ctz(rows); row.total_lines = rows * nb; row.line_stride = 0;
         row.in_group_stride = row.out_group_stride = cols;
@@ -466,6 +510,7 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
             a.in_group_stride = cols; a.in_elem_stride = R2 * cols;           // rows R2*n1 + n2
             a.out_group_stride = (i64)R1 * cols; a.out_elem_stride = cols;          // rows R1*n2 + k1
             a.tw_step = TW_N / rows;
+            a.tw_uniform = cols >= 64;     // launch_pass<true> puts at most 64 adjacent columns in a block
             rc = launch_pass<true>(R1, pin, pout, a, bytes, s);
             if (rc) return rc;
             FftGeo b = g;
@@ -604,6 +649,7 @@ static int pow2_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, in
     g.inverse = dir > 0;
     g.plane_stride = 0;
     g.tw_step = 0;
+    g.tw_uniform = 0;
     g.inner_log2 = 0; g.groups_log2 = 30; g.line_stride = 0;      // line index == group index
     g.in_group_stride = src_stride; g.out_group_stride = dst_stride;
     g.in_elem_stride = g.out_elem_stride = 1;

@@ -469,13 +469,16 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edi
     hipError_t e = hipMalloc(&d_img, n * 4);
     if (e == hipSuccess && ws_bytes) e = hipMalloc(&ws, ws_bytes);
     for (int c = 0; c < 3 && e == hipSuccess; c++) e = hipMalloc(&pl[c], n * 8);
+    // the transforms run out of place through `tmp`: tall planes take the fast split column pass there
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&tmp, n * 8);
     if (e == hipSuccess) e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = mi_u8_to_complex_dev(d_img, pl[0], pl[1], pl[2], w, h, nullptr);
         for (int c = 0; c < 3 && rc == MI_OK; c++) {
-            rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
-            if (rc == MI_OK) rc = edit(pl[c]);
-            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl[c], pl[c], h, w, 1, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
+            rc = mi_fft2d_c2c_f32_ws_dev(pl[c], tmp, h, w, 1, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
+            if (rc == MI_OK) rc = edit(tmp);
+            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(tmp, pl[c], h, w, 1, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
             if (rc == MI_OK) rc = mi_normalize_zero_imag_dev(pl[c], w, h, nullptr);
         }
         if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl[0], pl[1], pl[2], d_img, w, h, nullptr);
@@ -483,6 +486,7 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edi
     }
     if (d_img) (void)hipFree(d_img);
     if (ws) (void)hipFree(ws);
+    if (tmp) (void)hipFree(tmp);
     for (int c = 0; c < 3; c++) if (pl[c]) (void)hipFree(pl[c]);
     return rc ? rc : hip_status(e, "spectral round trip");
 }

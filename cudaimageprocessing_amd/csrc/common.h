@@ -193,6 +193,12 @@ struct RowIO<0> {
         else if (lane == 63) v = load_px4<0>(in, *g, (i64)row * g->W + cx + 4 * hop);
         return v;
     }
+    // the pixel just left of the strip (lane 0) / just right of it (lane 63); 0 elsewhere
+    MI_DEV u32 load_halo1(int row) const
+    {
+        const u32x4 h = load_halo(row, 1);
+        return lane == 0 ? h.w : h.x;
+    }
     MI_DEV void store(int y, u32x4 v) const { if (productive) store_px4<0>(out, *g, y, cx, v); }
 };
 
@@ -202,6 +208,7 @@ struct RowIO<1> {
     int in_off;    // byte offset of this lane's 4 pixels in row `row0`, relative to rin's base
     int halo_off;  // the same for the halo group one hop away (out of range for lanes 1..62)
     int halo_dir;  // -16 for lane 0, +16 for lane 63: byte step per extra hop
+    int halo1_off; // the single pixel next to the strip: in_off - 4 (lane 0), in_off + 16 (lane 63)
     u32 out_off;   // same for rout; 0x80000000 (out of range) for lanes that must not store
     int row0, ylo, pitch;
     MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g, const WaveJob& j, const March& m, int cx0, int margin = 0)
@@ -219,6 +226,7 @@ struct RowIO<1> {
         in_off = (int)((fmin + 8 - base) * 4) + 16 * j.lane;
         halo_dir = j.lane == 0 ? -16 : 16;
         halo_off = (j.lane == 0 || j.lane == 63) ? in_off + halo_dir : (int)0x80000000;
+        halo1_off = j.lane == 0 ? in_off - 4 : (j.lane == 63 ? in_off + 16 : (int)0x80000000);
         const i64 obase = (i64)ylo * g.W;
         rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (obase - g.out_origin)), 0, m.n * pitch, 0x00020000);
         const int cx = cx0 + 4 * j.lane;
@@ -231,6 +239,13 @@ struct RowIO<1> {
     MI_DEV u32x4 load_halo(int row, int hop) const
     {
         return __builtin_amdgcn_raw_buffer_load_b128(rin, (row - row0) * pitch + halo_off + (hop - 1) * halo_dir, 0, 0);
+    }
+    // One-pixel halo as a single dword load: a 3x3 filter uses nothing else of the halo group, and
+    // unused destination registers of a wider load would be reused by the compiler for
+    // temporaries, which makes the wave wait for the load right after issuing it.
+    MI_DEV u32 load_halo1(int row) const
+    {
+        return __builtin_amdgcn_raw_buffer_load_b32(rin, (row - row0) * pitch + halo1_off, 0, 0);
     }
     MI_DEV void store(int y, u32x4 v) const
     {   // aux 2 = nt: streaming store, the output is not read again by this kernel

@@ -99,24 +99,25 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g)
 {
     MI_MARCH_PROLOGUE();
-    // Red bytes of the halo pixels as one packed pair: low half = first pixel right of the strip
-    // (meaningful in lane 63), high half = last pixel left of it (meaningful in lane 0).
-    auto halo_red = [](u32x4 h) { return __builtin_amdgcn_perm(h.w, h.x, 0x0c040c00u); };
+    // Red byte of the halo pixel in both halves of a packed pair: the low half is what lane 63
+    // uses (first pixel right of the strip), the high half what lane 0 uses (last pixel left of it).
+    auto halo_red = [](u32 h) { return (h & 0xffu) * 0x00010001u; };
 
     u32 t01, t23, m01, m23, b01, b23, th, mh, bh;
     // t = oldest row of the window, b = newest.  Marching up swaps their roles, which only flips
     // the sign of Gy; Gx^2 + Gy^2 does not change.
     red_pairs(io.load(mch.row(-1)), t01, t23);
-    th = halo_red(io.load_halo(mch.row(-1), 1));
+    th = halo_red(io.load_halo1(mch.row(-1)));
     red_pairs(io.load(mch.row(0)), m01, m23);
-    mh = halo_red(io.load_halo(mch.row(0), 1));
-    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
+    mh = halo_red(io.load_halo1(mch.row(0)));
+    u32x4 nxt = io.load(mch.row(1));
+    u32 nxh = io.load_halo1(mch.row(1));
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
         red_pairs(nxt, b01, b23);
         bh = halo_red(nxh);
         nxt = io.load(mch.row(i + 2));   // one row ahead; deeper prefetch measured no gain
-        nxh = io.load_halo(mch.row(i + 2), 1);
+        nxh = io.load_halo1(mch.row(i + 2));
         const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
         const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
         const u32 VH = pk_add(pk_add(th, bh), pk_add(mh, mh));
@@ -178,14 +179,14 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     MI_MARCH_PROLOGUE();
 
     // horizontal 3-sums of one row, per pixel, as (lo, hi) packed pairs
-    auto hsum = [&](u32x4 p, u32x4 h, u32 (&hl)[4], u32 (&hh)[4]) {
+    auto hsum = [&](u32x4 p, u32 h, u32 (&hl)[4], u32 (&hh)[4]) {   // h: the one-pixel halo
         u32 lo[6], hi[6];
-        unpack_px(from_left(p.w, h.w), lo[0], hi[0]);
+        unpack_px(from_left(p.w, h), lo[0], hi[0]);
         unpack_px(p.x, lo[1], hi[1]);
         unpack_px(p.y, lo[2], hi[2]);
         unpack_px(p.z, lo[3], hi[3]);
         unpack_px(p.w, lo[4], hi[4]);
-        unpack_px(from_right(p.x, h.x), lo[5], hi[5]);
+        unpack_px(from_right(p.x, h), lo[5], hi[5]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             hl[k] = pk_add(pk_add(lo[k], lo[k + 1]), lo[k + 2]);
@@ -194,14 +195,15 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    hsum(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), tl, th);
-    hsum(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), ml, mh);
-    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
+    hsum(io.load(mch.row(-1)), io.load_halo1(mch.row(-1)), tl, th);
+    hsum(io.load(mch.row(0)), io.load_halo1(mch.row(0)), ml, mh);
+    u32x4 nxt = io.load(mch.row(1));
+    u32 nxh = io.load_halo1(mch.row(1));
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
         hsum(nxt, nxh, bl, bh);
         nxt = io.load(mch.row(i + 2));
-        nxh = io.load_halo(mch.row(i + 2), 1);
+        nxh = io.load_halo1(mch.row(i + 2));
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
         u32 o[4];
 #pragma unroll
@@ -241,24 +243,24 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
                                                       u32* __restrict__ out, const Geo g)
 {
     MI_MARCH_PROLOGUE();
-    const bool first_lane = j.lane == 0;
     constexpr u32 SEL_G = 0x0c050c01u;   // (byte 1 of src1) | (byte 1 of src0) << 16
 
     // slot layout: 0..3 = RB of own pixels, 4 = RB of the halo pixel (left of the strip in lane
     // 0, right of it in lane 63), 5 = G of pixels 0,1, 6 = G of pixels 2,3, 7 = G of the halo
     // pixels (low half: right halo, high half: left halo)
-    auto unpack = [&](u32x4 p, u32x4 h, u32 (&w)[8]) {
+    auto unpack = [&](u32x4 p, u32 h, u32 (&w)[8]) {   // h: the one-pixel halo
         w[0] = p.x & 0x00FF00FFu; w[1] = p.y & 0x00FF00FFu; w[2] = p.z & 0x00FF00FFu; w[3] = p.w & 0x00FF00FFu;
-        w[4] = (first_lane ? h.w : h.x) & 0x00FF00FFu;
+        w[4] = h & 0x00FF00FFu;
         w[5] = __builtin_amdgcn_perm(p.y, p.x, SEL_G);
         w[6] = __builtin_amdgcn_perm(p.w, p.z, SEL_G);
-        w[7] = __builtin_amdgcn_perm(h.w, h.x, SEL_G);
+        w[7] = __builtin_amdgcn_perm(h, h, SEL_G);
     };
 
     u32 win[3][8];
-    unpack(io.load(mch.row(-1)), io.load_halo(mch.row(-1), 1), win[0]);
-    unpack(io.load(mch.row(0)), io.load_halo(mch.row(0), 1), win[1]);
-    u32x4 nxt = io.load(mch.row(1)), nxh = io.load_halo(mch.row(1), 1);
+    unpack(io.load(mch.row(-1)), io.load_halo1(mch.row(-1)), win[0]);
+    unpack(io.load(mch.row(0)), io.load_halo1(mch.row(0)), win[1]);
+    u32x4 nxt = io.load(mch.row(1));
+    u32 nxh = io.load_halo1(mch.row(1));
     for (int base = 0; base < mch.n; base += 3) {
 #pragma unroll
         for (int s = 0; s < 3; s++) {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
             const int y = mch.row(i);
             unpack(nxt, nxh, win[(s + 2) % 3]);          // input step i+1
             nxt = io.load(mch.row(i + 2));
-            nxh = io.load_halo(mch.row(i + 2), 1);
+            nxh = io.load_halo1(mch.row(i + 2));
             // sort every 3-pixel column: lo <= mid <= hi
             u32 lo[8], mid[8], hi[8];
 #pragma unroll

@@ -14,6 +14,8 @@
 typedef unsigned int u32;
 typedef long long i64;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x3 __attribute__((ext_vector_type(3)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 __attribute__((aligned(4))) u32x4_u;  // a 16-byte vector at 4-byte alignment
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -193,6 +195,18 @@ struct RowIO<0> {
         else if (lane == 63) v = load_px4<0>(in, *g, (i64)row * g->W + cx + 4 * hop);
         return v;
     }
+    template <int NPX>
+    MI_DEV u32x4 load_halo_px(int row, int hop) const
+    {
+        const u32x4 h = load_halo(row, hop);
+        if (lane != 0 || NPX == 4) return h;
+        const u32 a[4] = {h.x, h.y, h.z, h.w};
+        u32x4 v = {0u, 0u, 0u, 0u};
+        v.x = a[4 - NPX];
+        if (NPX > 1) v.y = a[(5 - NPX) & 3];
+        if (NPX > 2) v.z = a[(6 - NPX) & 3];
+        return v;
+    }
     // the pixel just left of the strip (lane 0) / just right of it (lane 63); 0 elsewhere
     MI_DEV u32 load_halo1(int row) const
     {
@@ -209,6 +223,7 @@ struct RowIO<1> {
     int halo_off;  // the same for the halo group one hop away (out of range for lanes 1..62)
     int halo_dir;  // -16 for lane 0, +16 for lane 63: byte step per extra hop
     int halo1_off; // the single pixel next to the strip: in_off - 4 (lane 0), in_off + 16 (lane 63)
+    bool first_lane;
     u32 out_off;   // same for rout; 0x80000000 (out of range) for lanes that must not store
     int row0, ylo, pitch;
     MI_DEV RowIO(const u32* in_, u32* out_, const Geo& g, const WaveJob& j, const March& m, int cx0, int margin = 0)
@@ -225,6 +240,7 @@ struct RowIO<1> {
         rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
         in_off = (int)((fmin + 8 - base) * 4) + 16 * j.lane;
         halo_dir = j.lane == 0 ? -16 : 16;
+        first_lane = j.lane == 0;
         halo_off = (j.lane == 0 || j.lane == 63) ? in_off + halo_dir : (int)0x80000000;
         halo1_off = j.lane == 0 ? in_off - 4 : (j.lane == 63 ? in_off + 16 : (int)0x80000000);
         const i64 obase = (i64)ylo * g.W;
@@ -239,6 +255,28 @@ struct RowIO<1> {
     MI_DEV u32x4 load_halo(int row, int hop) const
     {
         return __builtin_amdgcn_raw_buffer_load_b128(rin, (row - row0) * pitch + halo_off + (hop - 1) * halo_dir, 0, 0);
+    }
+    // The NPX pixels of halo group `hop` nearest to the strip: lane 0 gets the group's last NPX
+    // pixels, lane 63 its first NPX, in elements 0..NPX-1 (the rest is 0).  Loading exactly what
+    // is used matters: unused destination registers of a wider load get reused for temporaries
+    // and the wave then waits for the load right after issuing it.
+    template <int NPX>
+    MI_DEV u32x4 load_halo_px(int row, int hop) const
+    {
+        const int off = (row - row0) * pitch + halo_off + (hop - 1) * halo_dir + (first_lane ? (4 - NPX) * 4 : 0);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if constexpr (NPX == 4) {
+            v = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        } else if constexpr (NPX == 3) {
+            const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rin, off, 0, 0);
+            v.x = t.x; v.y = t.y; v.z = t.z;
+        } else if constexpr (NPX == 2) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rin, off, 0, 0);
+            v.x = t.x; v.y = t.y;
+        } else {
+            v.x = __builtin_amdgcn_raw_buffer_load_b32(rin, off, 0, 0);
+        }
+        return v;
     }
     // One-pixel halo as a single dword load: a 3x3 filter uses nothing else of the halo group, and
     // unused destination registers of a wider load would be reused by the compiler for

@@ -344,14 +344,15 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 {
     constexpr int K = 2 * R + 1;
     constexpr int HOPS = (R + 3) / 4;   // 4-pixel groups needed beyond each edge of the strip
+    constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;   // pixels used of halo groups 1 and 2
     MI_MARCH_PROLOGUE();
 
     struct RowIn { u32x4 p, h1, h2; };
     auto load_row = [&](int row) {
         RowIn r;
         r.p = io.load(row);
-        r.h1 = io.load_halo(row, 1);
-        if (HOPS > 1) r.h2 = io.load_halo(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
+        r.h1 = io.template load_halo_px<N1>(row, 1);
+        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
         return r;
     };
 
@@ -361,18 +362,20 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
     auto hrow = [&](const RowIn& r, f32x2 (&h)[6]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
-        const u32 e1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
-        const u32 e2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+        // halo group pixels: element i is the group's pixel 4-N+i in lane 0 (left of the strip) and
+        // its pixel i in lane 63 (right of it); the shifts only read those two lanes' edge values
+        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             col[8 + k] = p[k];
-            col[4 + k] = from_left(p[k], e1[k]);
-            col[12 + k] = from_right(p[k], e1[k]);
+            col[4 + k] = from_left(p[k], k >= 4 - N1 ? a1[(k - (4 - N1)) & 3] : 0u);
+            col[12 + k] = from_right(p[k], k < N1 ? a1[k] : 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            col[k] = from_left(col[4 + k], e2[k]);
-            col[16 + k] = from_right(col[12 + k], e2[k]);
+            col[k] = from_left(col[4 + k], (HOPS > 1 && k >= 4 - N2) ? a2[(k - (4 - N2)) & 3] : 0u);
+            col[16 + k] = from_right(col[12 + k], (HOPS > 1 && k < N2) ? a2[k] : 0u);
         }
         float f[4 + 2 * R][3];
 #pragma unroll
@@ -450,32 +453,35 @@ __global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ i
 {
     constexpr int K = 2 * R + 1;
     constexpr int HOPS = (R + 3) / 4;
+    constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;   // pixels used of halo groups 1 and 2
     MI_MARCH_PROLOGUE();
 
     struct RowIn { u32x4 p, h1, h2; };
     auto load_row = [&](int row) {
         RowIn r;
         r.p = io.load(row);
-        r.h1 = io.load_halo(row, 1);
-        if (HOPS > 1) r.h2 = io.load_halo(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
+        r.h1 = io.template load_halo_px<N1>(row, 1);
+        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
         return r;
     };
     // h[2k] = (R,B) sums, h[2k+1] = (G,A) sums over columns k-R .. k+R, for the lane's pixel k
     auto hrow = [&](const RowIn& r, u32 (&h)[8]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
-        const u32 e1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
-        const u32 e2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+        // halo group pixels: element i is the group's pixel 4-N+i in lane 0 (left of the strip) and
+        // its pixel i in lane 63 (right of it); the shifts only read those two lanes' edge values
+        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             col[8 + k] = p[k];
-            col[4 + k] = from_left(p[k], e1[k]);
-            col[12 + k] = from_right(p[k], e1[k]);
+            col[4 + k] = from_left(p[k], k >= 4 - N1 ? a1[(k - (4 - N1)) & 3] : 0u);
+            col[12 + k] = from_right(p[k], k < N1 ? a1[k] : 0u);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            col[k] = from_left(col[4 + k], e2[k]);
-            col[16 + k] = from_right(col[12 + k], e2[k]);
+            col[k] = from_left(col[4 + k], (HOPS > 1 && k >= 4 - N2) ? a2[(k - (4 - N2)) & 3] : 0u);
+            col[16 + k] = from_right(col[12 + k], (HOPS > 1 && k < N2) ? a2[k] : 0u);
         }
         u32 lo[4 + 2 * R], hi[4 + 2 * R];
 #pragma unroll

@@ -409,11 +409,18 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 #pragma unroll
         for (int s = 0; s < K; s++) {
             const int i = base + s;
+            // the next row is requested on every step, valid or not (a load beyond the band is harmless):
+            // assigned unconditionally, `nxt` needs no merge at the end of the guarded block below, and
+            // so no register copy that would make the wave wait for the load it has just issued
+            // (only where registers allow both rows to be live: the wide kernels keep the load in the block)
+            constexpr bool EAGER = R <= 4;
+            const RowIn cur = nxt;
+            if constexpr (EAGER) nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
-            hrow(nxt, win[(K - 1 + s) % K]);
-            nxt = load_row(mch.row(i + R + 1));
+            hrow(cur, win[(K - 1 + s) % K]);
+            if constexpr (!EAGER) nxt = load_row(mch.row(i + R + 1));
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -511,11 +518,12 @@ __global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ i
 #pragma unroll
         for (int s = 0; s < K; s++) {
             const int i = base + s;
+            const RowIn cur = nxt;   // see gauss_sep_kernel: the next row is requested unconditionally
+            nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // rows y-R+t live in slot (s+t)%K; the newest one, y+R, replaces the row dropped last step
-            hrow(nxt, win[(K - 1 + s) % K]);
-            nxt = load_row(mch.row(i + R + 1));
+            hrow(cur, win[(K - 1 + s) % K]);
 #pragma unroll
             for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[(K - 1 + s) % K][e]);
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;

@@ -543,6 +543,96 @@ __global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ i
     }
 }
 
+// ============================================================================ Gaussian, direct (3x3 .. 7x7)
+// imageGaussianBlur, imageTools.cu:287-311, in the reference's own order -- ky outer, kx inner,
+// sum = fmaf(pixel, weight, sum) from 0, truncating store -- so the result is bit-exact against the
+// oracle, as a wave march: the K most recent rows stay in registers (own 4 pixels plus R neighbours
+// each side), every output row is K*K fused multiply-adds per pixel and channel.
+// All bands march down: the accumulation order over ky is part of the result.
+struct GaussW2 { float w[49]; };
+
+template <int R, int POL>
+__global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __restrict__ in,
+                                                                 u32* __restrict__ out, const Geo g,
+                                                                 const GaussW2 gw)
+{
+    constexpr int K = 2 * R + 1, NC = 4 + 2 * R;
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    const int cx = j.strip * 256 + 4 * j.lane;
+    March mch;
+    mch.ys = g.y_begin + j.band * g.rows_per_band;
+    mch.n = min(mch.ys + g.rows_per_band, g.y_end) - mch.ys;
+    mch.dir = 1;
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * 256);
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+
+    struct RowIn { u32x4 p, h; };
+    auto load_row = [&](int row) {
+        RowIn r;
+        r.p = io.load(row);
+        r.h = io.template load_halo_px<R>(row, 1);
+        return r;
+    };
+    // c[i] = the pixel of column i - R (i = 0 .. 3 + 2R): own 4 pixels plus R neighbours each side
+    auto columns = [&](const RowIn& r, u32 (&c)[NC]) {
+        u32 col[12];   // columns -4..7 at index c+4
+        const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+        const u32 a[4] = {r.h.x, r.h.y, r.h.z, r.h.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[4 + k] = p[k];
+            col[k] = from_left(p[k], k >= 4 - R ? a[(k - (4 - R)) & 3] : 0u);
+            col[8 + k] = from_right(p[k], k < R ? a[k] : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; i++) c[i] = col[4 - R + i];
+    };
+
+    // the window keeps packed pixels (K x (4+2R) registers); a row is widened to floats when the
+    // accumulation reaches it, so only one row of floats is live at a time
+    u32 win[K][NC];
+#pragma unroll
+    for (int i = 0; i < K - 1; i++) columns(load_row(mch.row(i - R)), win[i]);
+    RowIn nxt = load_row(mch.row(R));
+    for (int base = 0; base < mch.n; base += K) {
+#pragma unroll
+        for (int s = 0; s < K; s++) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
+            columns(nxt, win[(K - 1 + s) % K]);      // row y+R; row y-R+t lives in slot (s+t)%K
+            nxt = load_row(mch.row(i + R + 1));
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            float acc[4][3] = {};
+#pragma unroll
+            for (int t = 0; t < K; t++) {            // ky: top row first, as upstream
+                float f[NC][3];
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    const u32 v = win[(s + t) % K][q];
+                    f[q][0] = (float)(v & 0xffu);
+                    f[q][1] = (float)((v >> 8) & 0xffu);
+                    f[q][2] = (float)((v >> 16) & 0xffu);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int u = 0; u < K; u++)      // kx
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            acc[k][c] = __builtin_fmaf(f[k + u][c], gw.w[t * K + u], acc[k][c]);
+            }
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = ((u32)acc[k][0] | ((u32)acc[k][1] << 8) | ((u32)acc[k][2] << 16) | 0xFF000000u) & xm[k] & rowm;
+            io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+            }
+        }
+    }
+}
+
 // ============================================================================ fused chain
 // gray -> Gaussian 5x5 -> median 3x3 -> Sobel (BASELINE.json config 2) in one pass: 8 bytes of
 // HBM traffic per pixel instead of 32.  After the grayscale stage the three colour channels are
@@ -939,6 +1029,14 @@ static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u3
 #undef MI_L
 }
 
+template <int R>
+static void launch_gauss_direct(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const GaussW2& gw)
+{
+#define MI_L(P) gauss_direct_march_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+    MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+}
+
 // magic with (s * magic) >> 24 == s / k^2 for every s <= 255 k^2 and s * magic < 2^32, verified
 // exhaustively once per process (0 if there is none).
 static u32 mean_magic(int k)
@@ -1040,7 +1138,8 @@ int launch_filter(const FilterArgs& a)
     const int rows = a.y_end - a.y_begin;
 
     // generic one-thread-per-pixel kernels
-    const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT;
+    const bool direct_march = a.filter == MI_FILTER_GAUSSIAN_DIRECT && a.ksize >= 3 && a.ksize <= 7;
+    const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT && !direct_march;
     const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15);
     if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
@@ -1076,7 +1175,7 @@ int launch_filter(const FilterArgs& a)
     // A taller band amortises the row pass of a wide Gaussian over more output rows.
     int rpb = env_int("MI_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
-        const int r = (a.filter == MI_FILTER_GAUSSIAN || a.filter == MI_FILTER_MEAN) ? a.ksize / 2 : 1;
+        const int r = (a.filter == MI_FILTER_GAUSSIAN || a.filter == MI_FILTER_MEAN || direct_march) ? a.ksize / 2 : 1;
         rpb = r == 1 ? 6 : std::min(10 * r, 64);
         if (median5) rpb = 32;   // VALU-bound: amortise the 4 extra rows of a band
         // wide Gaussians: 2R extra row passes per band, two waves per SIMD -> taller bands, fewer waves
@@ -1130,6 +1229,16 @@ int launch_filter(const FilterArgs& a)
 #undef MI_L
     }
         break;
+    case MI_FILTER_GAUSSIAN_DIRECT: {
+        GaussW2 gw;
+        gaussian_kernel_2d(a.ksize, a.sigma, gw.w);
+        switch (a.ksize / 2) {
+        case 1: launch_gauss_direct<1>(pol, grid, a.stream, in, out, g, gw); break;
+        case 2: launch_gauss_direct<2>(pol, grid, a.stream, in, out, g, gw); break;
+        default: launch_gauss_direct<3>(pol, grid, a.stream, in, out, g, gw); break;
+        }
+        break;
+    }
     case MI_FILTER_GAUSSIAN: {
         GaussW gw;
         gaussian_kernel_1d(a.ksize, a.sigma, gw.w);

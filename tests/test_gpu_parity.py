@@ -142,7 +142,7 @@ def test_gaussian_separable_within_1_lsb(dev, golden, k, sigma):
     assert worst <= GAUSS_TOL
 
 
-@pytest.mark.parametrize("k,sigma", [(1, 0.5), (3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)])
+@pytest.mark.parametrize("k,sigma", [(1, 0.5), (3, 7.0), (5, 1.0), (7, 1.5), (9, 2.0), (15, 2.5)])
 def test_gaussian_direct_is_bit_exact(dev, golden, k, sigma):
     for (w, h) in ((67, 45), (64, 48), (5, 7), (256, 16)):
         img = S.synth_image(100 + k, w, h)
@@ -258,7 +258,11 @@ def test_decomposition_does_not_change_results(dev, monkeypatch):
     filter, the separable Gaussian included, gives bit-identical output for any choice."""
     img = ops.synth(77, 1920, 270)
     fns = {"sobel": ops.sobel, "mean": lambda t: ops.mean_blur(t, 3), "median": lambda t: ops.median_blur(t, 3),
-           "gauss5": lambda t: ops.gaussian_blur(t, 5, 1.0), "gauss15": lambda t: ops.gaussian_blur(t, 15, 2.5)}
+           "gauss5": lambda t: ops.gaussian_blur(t, 5, 1.0), "gauss15": lambda t: ops.gaussian_blur(t, 15, 2.5),
+           "median5": lambda t: ops.median_blur(t, 5), "mean7": lambda t: ops.mean_blur(t, 7),
+           "mean15": lambda t: ops.mean_blur(t, 15), "gauss11": lambda t: ops.gaussian_blur(t, 11, 2.0),
+           "direct5": lambda t: ops.gaussian_blur(t, 5, 1.0, direct=True),
+           "direct7": lambda t: ops.gaussian_blur(t, 7, 1.5, direct=True)}
     monkeypatch.setenv("MI_ROWS_PER_BAND", "32")
     monkeypatch.setenv("MI_CHAIN_ROWS_PER_BAND", "32")
     ref = {k: fn(img).clone() for k, fn in fns.items()}

@@ -60,7 +60,9 @@ report(f"median 3x3 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 3,
 report(f"median 5x5 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 5, out), 20, "VALU-bound")
 for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)):
     report(f"Gaussian {k}x{k} sigma {s}, separable ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out), 20)
-report(f"Gaussian 5x5, direct (bit-exact order) ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 5, 1.0, out, direct=True), 5, "one lane per pixel")
+for k, s in ((3, 7.0), (5, 1.0), (7, 1.5)):
+    report(f"Gaussian {k}x{k}, direct = the reference's summation order, bit-exact ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out, direct=True), 10, "VALU-bound: k*k fma per pixel and channel")
+report(f"Gaussian 9x9, direct, generic kernel ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 9, 2.0, out, direct=True), 3, "one lane per pixel (sizes above 7)")
 report(f"fused chain gray>gauss5>median3>Sobel ({C})", "C2 chain", px, 8, lambda: ops.fused_chain(fr, 1.0, out), None, "the four kernels move 32 B/px")
 bufs = [torch.empty_like(fr) for _ in range(3)] + [out]
 report(f"the same chain as four kernels ({C})", "C2 chain", px, 32, lambda: ops.filter_chain(fr, bufs))

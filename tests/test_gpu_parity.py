@@ -363,3 +363,45 @@ def test_device_load_write_copy(dev):
     assert torch.equal(back, img.reshape(-1))
     odd = flat[1:1 + 4 * 99]                     # a view: unaligned source pointer, byte path
     assert torch.equal(ops.image_load(odd), odd)
+
+
+# ------------------------------------------------------------------ randomized differential test
+def test_random_shapes_and_filters_against_oracle(dev, golden):
+    """120 seeded random (shape, filter, parameter, pattern) cases against the oracle: widths around the
+    strip widths (248, 256) and their multiples, heights around the band heights, both access
+    policies (widths that are and are not multiples of 4)."""
+    rng = np.random.default_rng(20240607)
+    special_w = [3, 4, 5, 7, 8, 247, 248, 249, 255, 256, 257, 260, 495, 496, 497, 511, 512, 513, 744, 768, 1000]
+    special_h = [3, 4, 5, 6, 7, 8, 11, 12, 13, 29, 30, 31, 32, 33, 59, 60, 61, 64, 65, 127, 128, 129]
+    for case in range(120):
+        w = int(rng.choice(special_w)) if rng.random() < 0.6 else int(rng.integers(3, 700))
+        h = int(rng.choice(special_h)) if rng.random() < 0.6 else int(rng.integers(3, 200))
+        kind = str(rng.choice(PATTERNS))
+        img = make(kind, w, h, int(rng.integers(1, 1 << 30)))
+        d = to_dev(img, dev)
+        what = int(rng.integers(0, 7))
+        tag = (case, w, h, kind, what)
+        if what == 0:
+            assert np.array_equal(host(ops.sobel(d)), golden.sobel(img)), tag
+        elif what == 1:
+            k = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17]))
+            assert np.array_equal(host(ops.mean_blur(d, k)), golden.meanblur(img, k)), tag + (k,)
+        elif what == 2:
+            k = int(rng.choice([3, 5]))
+            assert np.array_equal(host(ops.median_blur(d, k)), golden.medianblur(img, k)), tag + (k,)
+        elif what == 3:
+            k = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+            sigma = float(rng.uniform(0.6, 4.0))
+            got = host(ops.gaussian_blur(d, k, sigma)).astype(np.int16)
+            assert np.abs(got - golden.gaussian(img, k, sigma).astype(np.int16)).max() <= GAUSS_TOL, tag + (k, sigma)
+        elif what == 4:
+            k = int(rng.choice([3, 5, 7, 9]))
+            sigma = float(rng.uniform(0.6, 4.0))
+            assert np.array_equal(host(ops.gaussian_blur(d, k, sigma, direct=True)), golden.gaussian(img, k, sigma)), tag + (k, sigma)
+        elif what == 5:
+            assert np.array_equal(host(ops.grayscale(d)), golden.grayscale(img)), tag
+        else:
+            stages = ops.filter_chain(d)
+            assert torch.equal(ops.fused_chain(d), stages[3]), tag
+            assert np.array_equal(host(stages[2]), golden.medianblur(host(stages[1]), 3)), tag
+            assert np.array_equal(host(stages[3]), golden.sobel(host(stages[2]))), tag

@@ -3,11 +3,14 @@
 // pipeline.  The image is cut into row chunks; a chunk is staged into pinned memory, copied to
 // the device, run through the whole list of filters on the device (each stage's row range shrinks
 // by that filter's halo) and copied back, on one of two streams, while the host stages the next
-// chunk and unloads the previous one.  Pinned and device buffers are kept between calls.
+// chunk and a helper thread unloads the finished ones.  Pinned and device buffers are kept
+// between calls.
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -28,7 +31,8 @@ struct HostPipe {
     std::mutex mu;
     int device = -1;
     size_t cap_in = 0, cap_out = 0, cap_dev = 0;
-    Slot slot[2];
+    static constexpr int NSLOT = 3;
+    Slot slot[NSLOT];
 
     void release()
     {
@@ -114,24 +118,50 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     hipError_t e = g_pipe.reserve(in_rows_max * pitch, (size_t)chunk * pitch, in_rows_max * pitch);
     if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
 
+    constexpr int NSLOT = HostPipe::NSLOT;
     std::vector<Rows> need(n_ops + 1);
+    std::vector<Rows> out_rows(n_chunks);
     int rc = MI_OK;
-    Rows pending{0, 0};          // output rows of the previous chunk, still in its slot's pin_out
-    auto unload = [&](int slot_id, Rows r) -> hipError_t {
-        hipError_t err = hipEventSynchronize(g_pipe.slot[slot_id].done);
-        if (err == hipSuccess) memcpy(out + (size_t)r.lo * pitch, g_pipe.slot[slot_id].pin_out, (size_t)(r.hi - r.lo) * pitch);
-        return err;
+
+    // The unloading side: chunk c leaves its slot's pinned buffer for `out` once the device is done
+    // with it AND the main thread has staged chunk c+1 -- when `out` aliases `in`, chunk c+1's input
+    // reaches into the rows chunk c overwrites (never further: a chunk is at least halo_sum rows).
+    std::atomic<int> submitted{0}, unloaded{0};
+    std::atomic<bool> abort_flag{false};
+    hipError_t unload_err = hipSuccess;
+    auto unload_all = [&]() {
+        for (int c = 0; c < n_chunks; c++) {
+            while (submitted.load(std::memory_order_acquire) < std::min(c + 2, n_chunks)) {
+                if (abort_flag.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            Slot& s = g_pipe.slot[c % NSLOT];
+            const hipError_t err = hipEventSynchronize(s.done);
+            if (err != hipSuccess) { unload_err = err; abort_flag.store(true, std::memory_order_release); return; }
+            const Rows r = out_rows[c];
+            memcpy(out + (size_t)r.lo * pitch, s.pin_out, (size_t)(r.hi - r.lo) * pitch);
+            unloaded.store(c + 1, std::memory_order_release);
+        }
     };
+    // one chunk: nothing to overlap, stay on this thread
+    std::thread helper;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (n_chunks > 1) helper = std::thread([&] { (void)hipSetDevice(device); unload_all(); });
+
     for (int c = 0; c < n_chunks && rc == MI_OK && e == hipSuccess; c++) {
-        Slot& s = g_pipe.slot[c & 1];
+        Slot& s = g_pipe.slot[c % NSLOT];
+        // the slot's previous occupant (chunk c - NSLOT) must have left its pinned output buffer
+        while (unloaded.load(std::memory_order_acquire) < c - NSLOT + 1 && !abort_flag.load(std::memory_order_acquire))
+            std::this_thread::yield();
+        if (abort_flag.load(std::memory_order_acquire)) break;
         // rows each stage must produce, back to front
         need[n_ops] = Rows{c * chunk, std::min(h, (c + 1) * chunk)};
         for (int k = n_ops - 1; k >= 0; k--) {
             const int halo = filter_halo_rows(ops[k].filter, ops[k].ksize);
             need[k] = Rows{std::max(0, need[k + 1].lo - halo), std::min(h, need[k + 1].hi + halo)};
         }
-        // stage the input rows (the slot's previous occupant, chunk c-2, was unloaded already).
-        // When out aliases in, this must precede the unload of chunk c-1, whose rows it may read.
+        out_rows[c] = need[n_ops];
         memcpy(s.pin_in, in + (size_t)need[0].lo * pitch, (size_t)(need[0].hi - need[0].lo) * pitch);
         e = hipMemcpyAsync(s.dev[0], s.pin_in, (size_t)(need[0].hi - need[0].lo) * pitch, hipMemcpyHostToDevice, s.stream);
         int cur = 0;
@@ -149,11 +179,12 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
         if (rc == MI_OK && e == hipSuccess)
             e = hipMemcpyAsync(s.pin_out, s.dev[cur], (size_t)(need[n_ops].hi - need[n_ops].lo) * pitch, hipMemcpyDeviceToHost, s.stream);
         if (rc == MI_OK && e == hipSuccess) e = hipEventRecord(s.done, s.stream);
-        // while the device works on chunk c: unload chunk c-1
-        if (rc == MI_OK && e == hipSuccess && c > 0) e = unload((c - 1) & 1, pending);
-        pending = need[n_ops];
+        if (rc == MI_OK && e == hipSuccess) submitted.store(c + 1, std::memory_order_release);
     }
-    if (rc == MI_OK && e == hipSuccess) e = unload((n_chunks - 1) & 1, pending);
+    if (rc != MI_OK || e != hipSuccess) abort_flag.store(true, std::memory_order_release);
+    if (helper.joinable()) helper.join();
+    else if (rc == MI_OK && e == hipSuccess) unload_all();
+    if (rc == MI_OK && e == hipSuccess && unload_err != hipSuccess) e = unload_err;
     if (rc != MI_OK || e != hipSuccess) {
         // leave nothing in flight that still points at the staging buffers
         for (Slot& s : g_pipe.slot) if (s.stream) (void)hipStreamSynchronize(s.stream);

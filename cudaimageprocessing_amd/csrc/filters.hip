@@ -80,6 +80,9 @@ MI_DEV u32 sobel_mag(int s)
     return m > 255u ? 255u : m;
 }
 
+// (m, m, m, 255) from m <= 255 in one v_perm_b32: selector bytes 0 = m's byte 0, 0x0d = 0xFF
+MI_DEV u32 gray_opaque(u32 m) { return __builtin_amdgcn_perm(0u, m, 0x0d000000u); }
+
 MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
 {   // (r0 | r1<<16), (r2 | r3<<16): the red bytes of 4 pixels as packed u16
     r01 = __builtin_amdgcn_perm(p.y, p.x, 0x0c040c00u);
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
-            o[k] = (sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)) * 0x010101u | 0xFF000000u) & xm[k] & rowm;
+            o[k] = gray_opaque(sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false))) & xm[k] & rowm;
         }
         io.store(y, u32x4{o[0], o[1], o[2], o[3]});
         t01 = m01; t23 = m23; th = mh; m01 = b01; m23 = b23; mh = bh;
@@ -763,7 +766,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
-                    o[k] = sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)) * 0x010101u | 0xFF000000u;
+                    o[k] = gray_opaque(sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)));
                     if constexpr (EDGE) o[k] &= xm[k] & srow;
                 }
                 if (i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});

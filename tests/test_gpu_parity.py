@@ -405,3 +405,32 @@ def test_random_shapes_and_filters_against_oracle(dev, golden):
             assert torch.equal(ops.fused_chain(d), stages[3]), tag
             assert np.array_equal(host(stages[2]), golden.medianblur(host(stages[1]), 3)), tag
             assert np.array_equal(host(stages[3]), golden.sobel(host(stages[2]))), tag
+
+
+def test_config3_full_batch(dev):
+    """BASELINE.json config 3 at full size on one GPU: 4096 frames of 1920x1080 (34 GB in, 34 GB
+    out) through the fused chain and through the four kernels in one launch each; sampled frames
+    must equal the same frames processed alone (frame offsets beyond 2^32 bytes, 1.2 M waves)."""
+    w, h, b = 1920, 1080, 4096
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs 150 GiB of device memory")
+    frames = torch.empty((b, h, w, 4), dtype=torch.uint8, device=dev)
+    for f in range(0, b, 512):                     # one synthetic stream, cut into frames
+        frames[f:f + 512] = ops.synth(3, w, h, batch=512, first_idx=f * w * h, device=dev)
+    out = ops.fused_chain(frames)
+    t0, t1 = torch.empty_like(frames), torch.empty_like(frames)
+    sample = (0, 1, 2047, 2048, 4095)
+    ops.grayscale(frames, t0)
+    for f in sample:
+        assert torch.equal(t0[f], ops.grayscale(frames[f])), f
+    ops.gaussian_blur(t0, 5, 1.0, t1)
+    ops.median_blur(t1, 3, t0)
+    for f in sample:
+        assert torch.equal(t0[f], ops.median_blur(ops.gaussian_blur(ops.grayscale(frames[f]), 5, 1.0), 3)), f
+    ops.sobel(t0, t1)
+    assert torch.equal(out, t1)
+    for f in sample:
+        assert torch.equal(out[f], ops.fused_chain(frames[f])), f
+    del frames, out, t0, t1
+    torch.cuda.empty_cache()

@@ -337,6 +337,13 @@ int mi_fft2d_c2c_f32_ws_dev(const void* d_in, void* d_out, int rows, int cols, i
     size_t need = 0;
     int rc = mi_fft2d_workspace_bytes(rows, cols, &need);
     if (rc) return rc;
+    const bool pow2 = (rows & (rows - 1)) == 0 && (cols & (cols - 1)) == 0;
+    if (pow2 && (!d_workspace || workspace_bytes < need || d_in != d_out)) {
+        // powers of two: the workspace is optional (it only speeds up tall planes in place)
+        const size_t bytes = (size_t)rows * cols * 8 * batch;
+        if (d_in != d_out && overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping buffers");
+        return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream);
+    }
     if (need && (!d_workspace || workspace_bytes < need))
         return fail(MI_ERR_INVALID_ARG, "fft2d %dx%d needs a workspace of %zu bytes (got %zu)", rows, cols, need, d_workspace ? workspace_bytes : (size_t)0);
     const size_t bytes = (size_t)rows * cols * 8 * batch;

@@ -470,7 +470,7 @@ static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, u32 bytes,
     }
 }
 
-int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s)
+int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s, void* tmp)
 {
     int rc = ensure_twiddles(s);
     if (rc) return rc;
@@ -488,7 +488,11 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
     //   A: for every n2, FFT_R1 over n1 of x[R2*n1+n2], times W_R^(n2*k1), stored at row R1*n2+k1
     //   B: for every k1, FFT_R2 over n2 of rows R1*n2+k1, stored in place at rows k1+R1*k2
     // and the row transform runs last, in place (row and column transforms commute).
-    const bool split = in != out && rows >= 1024 && env_int("MI_FFT_SPLIT", 1);
+    // In place, the split needs one plane of scratch (`tmp`): A writes there, B works there, the
+    // row pass brings the plane back; without it the single long-column pass is used (half speed).
+    const bool via_tmp = in == out && tmp != nullptr;
+    const bool split = (in != out || via_tmp) && rows >= 1024 && env_int("MI_FFT_SPLIT", 1);
+    if (split && via_tmp) group = 1;
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);
         const c2* pin = (const c2*)in + (i64)b0 * plane;
@@ -511,15 +515,16 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
             a.out_group_stride = (i64)R1 * cols; a.out_elem_stride = cols;          // rows R1*n2 + k1
             a.tw_step = TW_N / rows;
             a.tw_uniform = cols >= 64;     // launch_pass<true> puts at most 64 adjacent columns in a block
-            rc = launch_pass<true>(R1, pin, pout, a, bytes, s);
+            c2* mid = via_tmp ? (c2*)tmp : pout;
+            rc = launch_pass<true>(R1, pin, mid, a, bytes, s);
             if (rc) return rc;
             FftGeo b = g;
             b.inner_log2 = __builtin_ctz(cols); b.groups_log2 = __builtin_ctz(R1); b.total_lines = cols * R1 * nb; b.line_stride = 1;
             b.in_group_stride = b.out_group_stride = cols;                          // rows k1 + R1*(.)
             b.in_elem_stride = b.out_elem_stride = R1 * cols;
-            rc = launch_pass<true>(R2, pout, pout, b, bytes, s);
+            rc = launch_pass<true>(R2, mid, mid, b, bytes, s);
             if (rc) return rc;
-            rc = launch_pass<false>(cols, pout, pout, row, bytes, s);
+            rc = launch_pass<false>(cols, mid, pout, row, bytes, s);
             if (rc) return rc;
         } else {
             rc = launch_pass<false>(cols, pin, pout, row, bytes, s);
@@ -712,13 +717,14 @@ int fft2d_size_supported(int rows, int cols)
 
 size_t fft2d_workspace_bytes(int rows, int cols)
 {
-    if (is_pow2(rows) && is_pow2(cols)) return 0;
+    // powers of two need none; tall planes transformed IN PLACE run at full speed with one plane of it
+    if (is_pow2(rows) && is_pow2(cols)) return rows >= 1024 ? (size_t)rows * cols * sizeof(c2) : 0;
     return (size_t)blue_layout(rows, cols).total * sizeof(c2);
 }
 
 int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws, hipStream_t s)
 {
-    if (is_pow2(rows) && is_pow2(cols)) return launch_fft2d(in, out, rows, cols, batch, dir, s);
+    if (is_pow2(rows) && is_pow2(cols)) return launch_fft2d(in, out, rows, cols, batch, dir, s, ws);
     int rc = ensure_twiddles(s);
     if (rc) return rc;
     const BlueLayout L = blue_layout(rows, cols);

@@ -49,7 +49,10 @@ int host_release();
 
 // FFT path
 int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);
-int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s);
+// tmp: optional scratch of one plane (rows*cols*8 bytes) that lets a tall plane (rows >= 1024) be
+// transformed in place at full speed; may be null.
+int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s,
+                 void* tmp = nullptr);
 // Any sizes (powers of two up to 8192, anything else up to 4096) with a caller workspace of
 // fft2d_workspace_bytes(rows, cols) bytes (0 when both are powers of two).
 int fft2d_size_supported(int rows, int cols);

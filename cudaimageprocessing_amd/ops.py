@@ -198,7 +198,9 @@ def fft2d(x, inverse=False, out=None, workspace=None):
         out = _torch().empty_like(x)
     direction = _lib.FFT_INVERSE if inverse else _lib.FFT_FORWARD
     need = fft2d_workspace_bytes(rows, cols)
-    if need == 0:
+    pow2 = (rows & (rows - 1)) == 0 and (cols & (cols - 1)) == 0
+    if need == 0 or (pow2 and (out.data_ptr() != x.data_ptr() or workspace is None)):
+        # powers of two: scratch is optional; it is used only when the caller brings it (in place, tall planes)
         check(lib().mi_fft2d_c2c_f32_dev(x.data_ptr(), out.data_ptr(), rows, cols, batch, direction, _stream()))
         return out
     if workspace is None:

@@ -141,9 +141,11 @@ int mi_fft2d_c2c_f32_dev(const void *d_in, void *d_out, int rows, int cols, int 
 /* cufftPlan2d + cufftExecC2C for any size (the reference plans whatever the image measures; its
  * demo input is 675x900, main.cpp:34-45): each of rows, cols is in [2, 4096], or a power of two
  * up to 8192.  Lengths that are not powers of two go through Bluestein's chirp-z transform and
- * need device scratch: mi_fft2d_workspace_bytes gives the size (0 when both are powers of two),
- * the caller owns the buffer (cuFFT keeps its work area inside the plan).  Calls sharing one
- * workspace must be stream-ordered. */
+ * need device scratch: mi_fft2d_workspace_bytes gives the size, the caller owns the buffer (cuFFT
+ * keeps its work area inside the plan).  For powers of two the workspace is optional: the size is
+ * 0 below 1024 rows and one plane (rows*cols*8) from 1024 rows on, where it lets an IN-PLACE
+ * transform run as fast as an out-of-place one (without it, in place, tall planes take a slower
+ * column pass).  Calls sharing one workspace must be stream-ordered. */
 int mi_fft2d_workspace_bytes(int rows, int cols, size_t *bytes);
 int mi_fft2d_c2c_f32_ws_dev(const void *d_in, void *d_out, int rows, int cols, int batch,
                             int direction, void *d_workspace, size_t workspace_bytes, void *stream);

@@ -225,26 +225,31 @@ int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* min
 
 // ---------------------------------------------------------------- compressImage support
 // Keep the `keep` coefficients of largest |X|^2 of a spectrum and zero the rest: the threshold
-// is the keep-th largest value, found exactly by a two-level radix select on the bit pattern of
-// |X|^2 (non-negative floats order like unsigned integers): a histogram of the upper 16 bits,
-// then of the lower 16 bits inside the bucket the threshold falls in.  Coefficients equal to the
-// threshold are all kept, so slightly more than `keep` can survive when values tie.
+// is the keep-th largest value, found exactly by a three-level radix select on the bit pattern of
+// |X|^2 (non-negative floats order like unsigned integers; bits 30..20, 19..9, 8..0): each level
+// histograms, in LDS per block, the next digit of the values that share the digits found so far.
+// Coefficients equal to the threshold are all kept, so slightly more than `keep` can survive
+// when values tie.
 MI_DEV u32 mag2_bits(f32x2v v) { return __float_as_uint(v.x * v.x + v.y * v.y); }
 
-__global__ __launch_bounds__(256) void mag_hist_hi_kernel(const f32x2v* __restrict__ d, i64 n, u32* __restrict__ hist)
-{
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        atomicAdd(&hist[mag2_bits(d[i]) >> 16], 1u);
-}
+constexpr int SEL_BINS = 2048;
 
-__global__ __launch_bounds__(256) void mag_hist_lo_kernel(const f32x2v* __restrict__ d, i64 n, u32 hi, u32* __restrict__ hist)
+// hist[digit] += 1 for every value whose bits above `shift + width` equal `prefix`
+__global__ __launch_bounds__(256) void mag_hist_kernel(const f32x2v* __restrict__ d, i64 n, u32 prefix,
+                                                       int prefix_shift, int shift, u32 digit_mask,
+                                                       u32* __restrict__ hist)
 {
+    __shared__ u32 local[SEL_BINS];
+    for (int b = threadIdx.x; b < SEL_BINS; b += 256) local[b] = 0;
+    __syncthreads();
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const u32 b = mag2_bits(d[i]);
-        if ((b >> 16) == hi) atomicAdd(&hist[b & 0xffffu], 1u);
+        if (prefix_shift >= 32 || (b >> prefix_shift) == prefix) atomicAdd(&local[(b >> shift) & digit_mask], 1u);
     }
+    __syncthreads();
+    for (int b = threadIdx.x; b < SEL_BINS; b += 256)
+        if (local[b]) atomicAdd(&hist[b], local[b]);
 }
 
 __global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i64 n, u32 threshold)
@@ -254,49 +259,43 @@ __global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i
         if (mag2_bits(d[i]) < threshold) d[i] = f32x2v{0.f, 0.f};
 }
 
-// Blocking: reads the two histograms back on the host.
+// Blocking: reads the three histograms back on the host.
 int spectrum_keep_top(void* data, size_t n, size_t keep, hipStream_t s)
 {
     if (keep >= n) return MI_OK;
+    const int grid = std::min(flat_grid((i64)n, 4), 1024);
+    if (keep == 0) {
+        mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, 0xffffffffu);   // nothing survives
+        return hip_status(hipGetLastError(), "spectrum_keep_top");
+    }
     u32* d_hist = nullptr;
-    hipError_t e = hipMalloc((void**)&d_hist, 65536 * sizeof(u32));
+    hipError_t e = hipMalloc((void**)&d_hist, SEL_BINS * sizeof(u32));
     if (e != hipSuccess) return hip_status(e, "spectrum histogram");
-    std::vector<u32> hist(65536);
-    const int grid = flat_grid((i64)n);
-    u32 threshold = 0;
-    // walks a histogram from the top bucket down; returns the bucket holding the `want`-th
-    // largest element and leaves in `want` its rank inside that bucket
-    auto find_bucket = [&](size_t& want) {
+    std::vector<u32> hist(SEL_BINS);
+    // digits, most significant first: (shift, width)
+    const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
+    u32 prefix = 0;
+    size_t want = keep;                 // rank of the threshold among the values sharing `prefix`, from the top
+    for (int level = 0; level < 3 && e == hipSuccess; level++) {
+        const int shift = shifts[level], prefix_shift = level == 0 ? 32 : shifts[level - 1];
+        e = hipMemsetAsync(d_hist, 0, SEL_BINS * sizeof(u32), s);
+        if (e != hipSuccess) break;
+        mag_hist_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, prefix, prefix_shift, shift,
+                                             (1u << widths[level]) - 1u, d_hist);
+        e = hipMemcpyAsync(hist.data(), d_hist, SEL_BINS * sizeof(u32), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
         size_t above = 0;
-        for (int b = 65535; b >= 0; b--) {
-            if (above + hist[b] >= want) { want -= above; return (u32)b; }
+        u32 digit = 0;
+        for (int b = (1 << widths[level]) - 1; b >= 0; b--) {
+            if (above + hist[b] >= want) { digit = (u32)b; want -= above; break; }
             above += hist[b];
         }
-        want = 1;
-        return 0u;
-    };
-    size_t want = keep == 0 ? 1 : keep;
-    e = hipMemsetAsync(d_hist, 0, 65536 * sizeof(u32), s);
-    if (e == hipSuccess) {
-        mag_hist_hi_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, d_hist);
-        e = hipMemcpyAsync(hist.data(), d_hist, 65536 * sizeof(u32), hipMemcpyDeviceToHost, s);
+        prefix = (prefix << widths[level]) | digit;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) {
-        const u32 hi = find_bucket(want);
-        e = hipMemsetAsync(d_hist, 0, 65536 * sizeof(u32), s);
-        if (e == hipSuccess) {
-            mag_hist_lo_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, hi, d_hist);
-            e = hipMemcpyAsync(hist.data(), d_hist, 65536 * sizeof(u32), hipMemcpyDeviceToHost, s);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess) {
-            const u32 lo = find_bucket(want);
-            threshold = (hi << 16) | lo;
-            if (keep == 0) threshold = 0xffffffffu;      // nothing survives
-            mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, threshold);
-            e = hipGetLastError();
-        }
+        mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, prefix);   // after three levels the prefix is the threshold
+        e = hipGetLastError();
     }
     (void)hipFree(d_hist);
     return hip_status(e, "spectrum_keep_top");

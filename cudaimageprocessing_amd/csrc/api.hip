@@ -467,34 +467,31 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edi
     int rc = check_image(in, out, w, h, 1);
     if (rc) return rc;
     const size_t n = (size_t)w * h;
-    void* d_img = nullptr;
-    void* pl[3] = {nullptr, nullptr, nullptr};
-    void* ws = nullptr;
     size_t ws_bytes = 0;
     rc = mi_fft2d_workspace_bytes(h, w, &ws_bytes);
     if (rc) return rc;
-    hipError_t e = hipMalloc(&d_img, n * 4);
-    if (e == hipSuccess && ws_bytes) e = hipMalloc(&ws, ws_bytes);
-    for (int c = 0; c < 3 && e == hipSuccess; c++) e = hipMalloc(&pl[c], n * 8);
-    // the transforms run out of place through `tmp`: tall planes take the fast split column pass there
-    void* tmp = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&tmp, n * 8);
-    if (e == hipSuccess) e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
+    // one cached device buffer: the image, three planes, three planes of spectrum (the transforms run out
+    // of place, where tall planes take the fast split column pass), the chirp-z workspace
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t img_bytes = up(n * 4), planes_bytes = up(n * 8 * 3);
+    HostScratch scratch;
+    rc = host_scratch(img_bytes + 2 * planes_bytes + ws_bytes, &scratch);
+    if (rc) return rc;
+    char* base = (char*)scratch.ptr;
+    void* d_img = base;
+    char* pl = base + img_bytes;
+    char* spec = pl + planes_bytes;
+    void* ws = ws_bytes ? spec + planes_bytes : nullptr;
+    hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = mi_u8_to_complex_dev(d_img, pl[0], pl[1], pl[2], w, h, nullptr);
-        for (int c = 0; c < 3 && rc == MI_OK; c++) {
-            rc = mi_fft2d_c2c_f32_ws_dev(pl[c], tmp, h, w, 1, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
-            if (rc == MI_OK) rc = edit(tmp);
-            if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(tmp, pl[c], h, w, 1, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
-            if (rc == MI_OK) rc = mi_normalize_zero_imag_dev(pl[c], w, h, nullptr);
-        }
-        if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl[0], pl[1], pl[2], d_img, w, h, nullptr);
+        rc = mi_u8_to_complex_dev(d_img, pl, pl + n * 8, pl + 2 * n * 8, w, h, nullptr);
+        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl, spec, h, w, 3, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
+        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = edit(spec + c * n * 8);
+        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(spec, pl, h, w, 3, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
+        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = mi_normalize_zero_imag_dev(pl + c * n * 8, w, h, nullptr);
+        if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
     }
-    if (d_img) (void)hipFree(d_img);
-    if (ws) (void)hipFree(ws);
-    if (tmp) (void)hipFree(tmp);
-    for (int c = 0; c < 3; c++) if (pl[c]) (void)hipFree(pl[c]);
     return rc ? rc : hip_status(e, "spectral round trip");
 }
 

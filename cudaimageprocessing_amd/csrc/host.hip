@@ -89,6 +89,21 @@ struct HostPipe {
 
 HostPipe g_pipe;
 
+// device scratch of the host-tier spectral calls (grow-only, one device at a time)
+struct Scratch {
+    std::mutex mu;
+    int device = -1;
+    void* ptr = nullptr;
+    size_t cap = 0;
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0; device = -1;
+    }
+};
+
+Scratch g_scratch;
+
 struct Rows { int lo, hi; };
 
 }  // namespace
@@ -97,6 +112,25 @@ int host_release()
 {
     std::lock_guard<std::mutex> lock(g_pipe.mu);
     g_pipe.release();
+    std::lock_guard<std::mutex> lock2(g_scratch.mu);
+    g_scratch.release();
+    return MI_OK;
+}
+
+int host_scratch(size_t bytes, HostScratch* out)
+{
+    out->lock = std::unique_lock<std::mutex>(g_scratch.mu);
+    out->ptr = nullptr;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_status(e, "host-tier scratch");
+    if (dev != g_scratch.device || bytes > g_scratch.cap) {
+        g_scratch.release();
+        if ((e = hipMalloc(&g_scratch.ptr, bytes)) != hipSuccess) return hip_status(e, "host-tier scratch");
+        g_scratch.cap = bytes;
+        g_scratch.device = dev;
+    }
+    out->ptr = g_scratch.ptr;
     return MI_OK;
 }
 

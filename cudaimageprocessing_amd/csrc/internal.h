@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/mi_imagetools.h"
 
 namespace mi {
@@ -46,6 +48,13 @@ int launch_sobel_table(void* out, uint32_t count, hipStream_t s);
 int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops,
                  int chunk_rows_hint);
 int host_release();
+// Device scratch of at least `bytes` for a blocking host-tier call, kept between calls (freed by
+// host_release).  The holder of `lock` owns the buffer: host-tier spectral calls serialise on it.
+struct HostScratch {
+    std::unique_lock<std::mutex> lock;
+    void* ptr = nullptr;
+};
+int host_scratch(size_t bytes, HostScratch* out);
 
 // FFT path
 int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);

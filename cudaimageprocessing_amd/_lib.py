@@ -31,6 +31,7 @@ SIGNATURES = {
     "mi_filter_halo_rows": [_i, _i],
     "mi_synth_u8x4_dev": [_vp, _u64, _u64, _u64, _vp],
     "mi_debug_sobel_mag_table_dev": [_vp, _u32, _vp],
+    "mi_debug_sobel_mag_pairs_dev": [_vp, _i, _i, _vp],
     "mi_u8_to_complex_dev": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mi_fft2d_c2c_f32_dev": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mi_fft2d_workspace_bytes": [_i, _i, _vp],

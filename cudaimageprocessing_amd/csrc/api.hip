@@ -291,6 +291,13 @@ int mi_debug_sobel_mag_table_dev(void* d_out_u8, uint32_t count, void* stream)
     return launch_sobel_table(d_out_u8, count, (hipStream_t)stream);
 }
 
+int mi_debug_sobel_mag_pairs_dev(void* d_out_u8, int gmax, int variant, void* stream)
+{
+    if (!d_out_u8) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (gmax < 0 || gmax > 1020) return fail(MI_ERR_INVALID_ARG, "gmax must be in [0, 1020]");
+    return launch_sobel_pairs(d_out_u8, gmax, variant, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- FFT path, device tier
 static int check_plane(const void* p, int w, int h)
 {

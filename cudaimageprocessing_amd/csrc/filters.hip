@@ -152,6 +152,41 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
     }
 }
 
+// The fused chain carries its median and Sobel rows as packed f16 pairs (every value there is an
+// integer of magnitude <= 1020, exact in f16; non-negative f16 values order like their bit
+// patterns, so the median's packed u16 min/max work on them unchanged).  With (Gx, Gy) as one
+// f16 pair, s + 0.5 is a single dot2 with the 0.5 as its accumulator -- exact in f32 -- and the
+// magnitude is the same min(255, (uint)sqrt(s + 0.5f)) as above.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+MI_DEV u32 sobel_mag_h(u32 gxgy)
+{
+    const h16x2 v = __builtin_bit_cast(h16x2, gxgy);
+    const float d = __builtin_amdgcn_fdot2(v, v, 0.5f, false);
+    const float f = __builtin_amdgcn_sqrtf(d);
+    u32 m = (u32)f;
+    return m > 255u ? 255u : m;
+}
+
+MI_DEV u32 pk_f16(float lo, float hi) { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
+MI_DEV u32 h_add(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(h16x2, a) + __builtin_bit_cast(h16x2, b)); }
+MI_DEV u32 h_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(h16x2, a) - __builtin_bit_cast(h16x2, b)); }
+// 2a + b
+MI_DEV u32 h_fma2(u32 a, u32 b)
+{
+    const h16x2 two = {(_Float16)2.0f, (_Float16)2.0f};
+    return __builtin_bit_cast(u32, __builtin_elementwise_fma(two, __builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b)));
+}
+
+// out[(gy + gmax) * (2 gmax + 1) + gx + gmax] = the magnitude of (gx, gy)
+__global__ void sobel_pairs_kernel(unsigned char* out, int gmax, int variant)
+{
+    const int n = 2 * gmax + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const h16x2 v = {(_Float16)(float)(i % n - gmax), (_Float16)(float)(i / n - gmax)};
+    out[i] = (unsigned char)sobel_mag_h(__builtin_bit_cast(u32, v));
+}
+
 __global__ void sobel_table_kernel(unsigned char* out, u32 count)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,9 +268,15 @@ MI_DEV void sort2(u32& a, u32& b)
     const u32 lo = pk_min(a, b), hi = pk_max(a, b);
     a = lo; b = hi;
 }
+// Median of three per 16-bit half.  There is no packed median, but v_med3_u16 on each half
+// (op_sel picks the high halves and writes the high half of the destination, keeping the low
+// one) is two operations where the packed min/max network takes four.
 MI_DEV u32 med3(u32 a, u32 b, u32 c)
 {
-    return pk_max(pk_min(a, b), pk_min(pk_max(a, b), c));
+    u32 d;
+    asm("v_med3_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_med3_u16 %0, %1, %2, %3 op_sel:[1,1,1,1]" : "+v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 
 // Register layout: R and B of each pixel share a register (R | B<<16), the G bytes of two
@@ -644,44 +685,51 @@ __global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __re
 // the arithmetic of each stage is the single-filter kernel's own, operation for operation, and
 // each stage's output is zeroed outside the reference's write set before the next stage reads
 // it, so the result is bit-identical to running the four kernels one after the other.
-// The stages have a combined reach of 4 pixels: strips overlap by one lane on each side
-// (62 productive lanes) and a band reads 4 extra rows above and below.
-template <int POL>
+// The stages have a combined reach of 4 pixels: strips overlap by MRG >= 1 lanes on each side
+// (64 - 2 MRG productive lanes) and a band reads 4 extra rows above and below.
+template <int POL, int MRG>
 __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g,
                                                     const GaussW gw)
 {
     const WaveJob j = wave_job(g);
     if (!j.valid) return;
-    constexpr int OUTW = 4 * 62;
-    const int cx = j.strip * OUTW - 4 + 4 * j.lane;
+    constexpr int OUTW = 4 * (64 - 2 * MRG);
+    const int cx = j.strip * OUTW - 4 * MRG + 4 * j.lane;
     const March mch = make_march(g, j);
-    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4, 1);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * MRG, MRG);
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
     const u32 pm01 = (xm[0] & 0xFFFFu) | (xm[1] & 0xFFFF0000u), pm23 = (xm[2] & 0xFFFFu) | (xm[3] & 0xFFFF0000u);
     auto rowmask = [&](int y) { return (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u; };
 
     // stage 1+2a: grayscale of 4 pixels (as floats holding integers), then the Gaussian row pass
-    auto gray_hrow = [&](u32x4 p, float (&h)[4]) {
+    // (two pixels per packed fp32 operation; each lane of a packed operation is the scalar one)
+    auto gray_hrow = [&](u32x4 p, f32x2 (&h)[2]) {
         float f[8];
         const u32 px[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float r = (float)(px[k] & 0xffu), gg = (float)((px[k] >> 8) & 0xffu), b = (float)((px[k] >> 16) & 0xffu);
-            const float t = 0.587f * gg;
-            const float u = __builtin_fmaf(0.299f, r, t);
-            f[2 + k] = __builtin_floorf(__builtin_fmaf(0.114f, b, u));   // == (float)(uchar)v, v >= 0
+        for (int q = 0; q < 2; q++) {
+            const u32 a = px[2 * q], b = px[2 * q + 1];
+            const f32x2 r = {(float)(a & 0xffu), (float)(b & 0xffu)};
+            const f32x2 gg = {(float)((a >> 8) & 0xffu), (float)((b >> 8) & 0xffu)};
+            const f32x2 bl = {(float)((a >> 16) & 0xffu), (float)((b >> 16) & 0xffu)};
+            const f32x2 t = 0.587f * gg;
+            const f32x2 u = __builtin_elementwise_fma((f32x2)(0.299f), r, t);
+            const f32x2 v = __builtin_elementwise_fma((f32x2)(0.114f), bl, u);
+            f[2 + 2 * q] = __builtin_floorf(v.x);        // == (float)(uchar)v, v >= 0
+            f[3 + 2 * q] = __builtin_floorf(v.y);
         }
         f[0] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[4])));
         f[1] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[5])));
         f[6] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[2])));
         f[7] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[3])));
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float s = gw.w[0] * f[k];
+        for (int q = 0; q < 2; q++) {
+            f32x2 sum = gw.w[0] * f32x2{f[2 * q], f[2 * q + 1]};
 #pragma unroll
-            for (int t = 1; t < 5; t++) s = __builtin_fmaf(gw.w[t], f[k + t], s);
-            h[k] = s;
+            for (int t = 1; t < 5; t++)
+                sum = __builtin_elementwise_fma((f32x2)(gw.w[t]), f32x2{f[2 * q + t], f[2 * q + 1 + t]}, sum);
+            h[q] = sum;
         }
     };
 
@@ -689,13 +737,13 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
     // write set needs none of the per-stage zeroing masks: they are all ones there.  Most waves
     // are such interior waves; the branch is wave-uniform and the two bodies are the same code
     // otherwise, so the result does not depend on which one runs.
-    const int x_first = j.strip * OUTW - 4, y_lo = (mch.dir > 0 ? mch.ys : mch.ys - (mch.n - 1));
+    const int x_first = j.strip * OUTW - 4 * MRG, y_lo = (mch.dir > 0 ? mch.ys : mch.ys - (mch.n - 1));
     const bool interior = x_first >= 1 && x_first + 255 <= g.W - 2 && y_lo - 4 >= 1 && y_lo + mch.n - 1 + 4 <= g.H - 2;
     auto run = [&](auto edge_tag) {
     constexpr bool EDGE = decltype(edge_tag)::value;
-    float win[5][4];
+    f32x2 win[5][2];
     // Gaussian output rows (the median's window) and median output rows (Sobel's window) as
-    // packed u16 pairs, in rings indexed by step mod 5 like `win`: with the loop unrolled by 5
+    // packed f16 pairs (see sobel_mag_h), in rings indexed by step mod 5 like `win`: with the loop unrolled by 5
     // every index is a compile-time constant and no row is ever copied
     u32 G01[5] = {0, 0, 0, 0, 0}, G23[5] = {0, 0, 0, 0, 0}, M01[5] = {0, 0, 0, 0, 0}, M23[5] = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -712,15 +760,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
             nxt = io.load(mch.row(i + 1));
             // ---- Gaussian column pass: row(i-2), zero outside the write set
             const u32 grow = rowmask(mch.row(i - 2));
-            u32 b[4];
+            float fb[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float a = gw.w[2] * win[(s + 2) % 5][k];
-                a = __builtin_fmaf(gw.w[0], win[s % 5][k] + win[(s + 4) % 5][k], a);
-                a = __builtin_fmaf(gw.w[1], win[(s + 1) % 5][k] + win[(s + 3) % 5][k], a);
-                b[k] = (u32)a;
+            for (int q = 0; q < 2; q++) {
+                f32x2 a = gw.w[2] * win[(s + 2) % 5][q];
+                a = __builtin_elementwise_fma((f32x2)(gw.w[0]), win[s % 5][q] + win[(s + 4) % 5][q], a);
+                a = __builtin_elementwise_fma((f32x2)(gw.w[1]), win[(s + 1) % 5][q] + win[(s + 3) % 5][q], a);
+                fb[2 * q] = __builtin_truncf(a.x);
+                fb[2 * q + 1] = __builtin_truncf(a.y);
             }
-            u32 gb01 = b[0] | (b[1] << 16), gb23 = b[2] | (b[3] << 16);
+            u32 gb01 = pk_f16(fb[0], fb[1]), gb23 = pk_f16(fb[2], fb[3]);
             if constexpr (EDGE) { gb01 &= pm01 & grow; gb23 &= pm23 & grow; }
             G01[s] = gb01; G23[s] = gb23;
             // ---- median 3x3: row(i-3) from the Gaussian rows of steps i-2, i-1, i
@@ -744,9 +793,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
             // ---- Sobel: row(i-4) from the median rows of steps i-2, i-1, i
             {
                 const u32 mt01 = M01[(s + 3) % 5], mt23 = M23[(s + 3) % 5], mm01 = M01[(s + 4) % 5], mm23 = M23[(s + 4) % 5];
-                const u32 V01 = pk_add(pk_add(mt01, med01), pk_add(mm01, mm01));
-                const u32 V23 = pk_add(pk_add(mt23, med23), pk_add(mm23, mm23));
-                const u32 D01 = pk_sub(med01, mt01), D23 = pk_sub(med23, mt23);
+                const u32 V01 = h_fma2(mm01, h_add(mt01, med01)), V23 = h_fma2(mm23, h_add(mt23, med23));
+                const u32 D01 = h_sub(med01, mt01), D23 = h_sub(med23, mt23);
                 const u32 VL = from_left(V23), VR = from_right(V01);
                 const u32 DL = from_left(D23), DR = from_right(D01);
                 const u32 Va = __builtin_amdgcn_alignbit(V01, VL, 16);
@@ -755,9 +803,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 const u32 Da = __builtin_amdgcn_alignbit(D01, DL, 16);
                 const u32 Db = __builtin_amdgcn_alignbit(D23, D01, 16);
                 const u32 Dc = __builtin_amdgcn_alignbit(DR, D23, 16);
-                const u32 Gx01 = pk_sub(Vb, Va), Gx23 = pk_sub(Vc, Vb);
-                const u32 Gy01 = pk_add(pk_add(Da, Db), pk_add(D01, D01));
-                const u32 Gy23 = pk_add(pk_add(Db, Dc), pk_add(D23, D23));
+                const u32 Gx01 = h_sub(Vb, Va), Gx23 = h_sub(Vc, Vb);
+                const u32 Gy01 = h_fma2(D01, h_add(Da, Db)), Gy23 = h_fma2(D23, h_add(Db, Dc));
                 const u32 P[4] = {__builtin_amdgcn_perm(Gy01, Gx01, 0x05040100u), __builtin_amdgcn_perm(Gy01, Gx01, 0x07060302u),
                                   __builtin_amdgcn_perm(Gy23, Gx23, 0x05040100u), __builtin_amdgcn_perm(Gy23, Gx23, 0x07060302u)};
                 const int y = mch.row(i - 4);
@@ -765,11 +812,13 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 u32 o[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const s16x2 v = __builtin_bit_cast(s16x2, P[k]);
-                    o[k] = gray_opaque(sobel_mag(__builtin_amdgcn_sdot2(v, v, 0, false)));
+                    o[k] = gray_opaque(sobel_mag_h(P[k]));
                     if constexpr (EDGE) o[k] &= xm[k] & srow;
                 }
-                if (i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+                // the first four steps complete rows of the neighbouring band: the buffer form drops
+                // them by itself (its descriptor spans this band's rows only), and with no branch
+                // here the next row's load stays at the top of the step
+                if (POL == 1 || i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});
             }
             }
         }
@@ -1016,6 +1065,13 @@ int launch_sobel_table(void* out, uint32_t count, hipStream_t s)
     return hip_status(hipGetLastError(), "sobel table kernel launch");
 }
 
+int launch_sobel_pairs(void* out, int gmax, int variant, hipStream_t s)
+{
+    const int n = 2 * gmax + 1;
+    sobel_pairs_kernel<<<(n * n + 255) / 256, 256, 0, s>>>((unsigned char*)out, gmax, variant);
+    return hip_status(hipGetLastError(), "sobel pairs kernel launch");
+}
+
 int filter_halo_rows(int filter, int ksize)
 {
     switch (filter) {
@@ -1091,9 +1147,15 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     g.N = (i64)W * H;
     g.in_origin = 0; g.in_lo = 0; g.in_hi = g.N; g.out_origin = 0;
     g.in_frame_stride = g.N; g.out_frame_stride = g.N;
-    g.strips = (W + 247) / 248;
-    // VALU-bound, not HBM-bound: tall bands amortise the 8 extra rows a band runs through the
-    // early stages; shrink them only to fill the machine
+    // margin lanes per side: one is enough for the chain's 4-pixel reach; two make the strips 240
+    // pixels wide, whose rows start on 64-byte boundaries (+3 % measured), and are taken when that
+    // costs no extra strip (3840 = 16 x 240, 1920 = 8 x 240)
+    int mrg = env_int("MI_CHAIN_MARGIN", 0);
+    if (mrg != 1 && mrg != 2) mrg = (W + 239) / 240 <= (W + 247) / 248 ? 2 : 1;
+    const int outw = 4 * (64 - 2 * mrg);
+    g.strips = (W + outw - 1) / outw;
+    // tall bands amortise the 8 extra rows a band runs through the early stages (measured flat
+    // between 24 and 36 rows, slower beyond); shrink them only to fill the machine
     int rpb = env_int("MI_CHAIN_ROWS_PER_BAND", 0);
     if (rpb <= 0) {
         rpb = 30;
@@ -1109,8 +1171,9 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     GaussW gw;
     gaussian_kernel_1d(5, sigma, gw.w);
     const int grid = (int)((total + 3) / 4);
-    if (aligned) chain_kernel<1><<<grid, 256, 0, stream>>>(in, out, g, gw);
-    else chain_kernel<0><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    if (!aligned) chain_kernel<0, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    else if (mrg == 2) chain_kernel<1, 2><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    else chain_kernel<1, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
     return hip_status(hipGetLastError(), "chain kernel launch");
 }
 

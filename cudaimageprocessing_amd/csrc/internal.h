@@ -42,6 +42,7 @@ void gaussian_kernel_1d(int k, float sigma, float* out);
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 int launch_synth(void* out, uint64_t seed, uint64_t first, uint64_t count, hipStream_t s);
 int launch_sobel_table(void* out, uint32_t count, hipStream_t s);
+int launch_sobel_pairs(void* out, int gmax, int variant, hipStream_t s);
 
 // Host tier (host.hip): run `n_ops` filters over a host image through the staging pipeline;
 // chunk_rows_hint <= 0 picks the chunk height.  host_release frees the cached buffers.

@@ -140,6 +140,14 @@ def sobel_mag_table(count, device="cuda"):
     return out
 
 
+def sobel_mag_pairs(gmax, variant=0, device="cuda"):
+    torch = _torch()
+    n = 2 * gmax + 1
+    out = torch.empty((n, n), dtype=torch.uint8, device=device)
+    check(lib().mi_debug_sobel_mag_pairs_dev(out.data_ptr(), gmax, variant, _stream()))
+    return out
+
+
 def image_load(byte_tensor, out=None):
     torch = _torch()
     n_px = byte_tensor.numel() // 4

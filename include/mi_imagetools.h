@@ -125,6 +125,12 @@ int mi_synth_u8x4_dev(void *d_out, uint64_t seed, uint64_t first_idx, uint64_t c
  * (uint8 per entry); lets a test sweep every reachable s.  Debug aid, not in the reference. */
 int mi_debug_sobel_mag_table_dev(void *d_out_u8, uint32_t count, void *stream);
 
+/* The same for the fused chain's form of the magnitude, which takes (Gx, Gy) as a pair of f16:
+ * out[(gy + gmax) * (2 gmax + 1) + gx + gmax] for gx, gy in [-gmax, gmax], gmax <= 1020 (the
+ * largest |Gx|, |Gy| a Sobel of bytes can reach).  variant 0 = the one the chain uses.
+ * Debug aid, not in the reference. */
+int mi_debug_sobel_mag_pairs_dev(void *d_out_u8, int gmax, int variant, void *stream);
+
 /* ---------------------------------------------------------------- FFT path (device tier)
  * Complex planes are interleaved fp32 (re,im), `rows` x `cols`, row-major (cufftComplex). */
 

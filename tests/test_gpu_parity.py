@@ -83,6 +83,19 @@ def test_sobel_magnitude_every_reachable_sum(dev):
     assert np.array_equal(got.astype(np.int64), expect)
 
 
+@pytest.mark.parametrize("variant", [0])
+def test_sobel_magnitude_of_every_gradient_pair_in_the_chain_form(dev, variant):
+    # the fused chain evaluates the magnitude from (Gx, Gy) as f16 pairs: all 2041 x 2041 pairs
+    g = np.arange(-1020, 1021, dtype=np.int64)
+    s = g[None, :] ** 2 + g[:, None] ** 2
+    expect = np.floor(np.sqrt(s.astype(np.float64))).astype(np.int64)
+    expect = np.where((expect + 1) ** 2 <= s, expect + 1, expect)
+    expect = np.where(expect ** 2 > s, expect - 1, expect)
+    expect = np.minimum(255, expect)
+    got = host(ops.sobel_mag_pairs(1020, variant)).astype(np.int64)
+    assert np.array_equal(got, expect)
+
+
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("kind", ["random", "natural", "binary", "gradient"])
 def test_sobel(dev, golden, w, h, kind):

@@ -498,8 +498,15 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 // packed u16 pairs ((R,B) and (G,A) of a pixel; a row sum is at most 15*255), a running column
 // sum over the K most recent row sums (at most 225*255 = 57375, still 16 bits), and the division
 // as (s * ceil(2^24 / k^2)) >> 24, which is exact for every reachable s (checked at launch).
+// high 32 bits of the product of two values below 2^24 (v_mul_hi_u32_u24: the operands are masked
+// so that the compiler can prove the range)
+MI_DEV u32 mulhi_u24(u32 a, u32 b)
+{
+    return (u32)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32);
+}
+
 template <int R, int POL>
-__global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ in,
+__global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u32* __restrict__ in,
                                                        u32* __restrict__ out, const Geo g,
                                                        const u32 magic)
 {
@@ -575,9 +582,11 @@ __global__ __launch_bounds__(256) void mean_sep_kernel(const u32* __restrict__ i
             u32 o[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u32 qr = ((cs[2 * k] & 0xFFFFu) * magic) >> 24;
-                const u32 qb = ((cs[2 * k] >> 16) * magic) >> 24;
-                const u32 qg = ((cs[2 * k + 1] & 0xFFFFu) * magic) >> 24;
+                // (s * magic) >> 24 as the high word of the 24-bit product (s << 8) * magic: s < 2^16 and
+                // magic < 2^24, and v_mul_hi_u32_u24 runs at full rate where a 32-bit multiply takes four slots
+                const u32 qr = mulhi_u24((cs[2 * k] & 0xFFFFu) << 8, magic);
+                const u32 qb = mulhi_u24((cs[2 * k] >> 16) << 8, magic);
+                const u32 qg = mulhi_u24((cs[2 * k + 1] & 0xFFFFu) << 8, magic);
                 o[k] = (qr | (qg << 8) | (qb << 16) | 0xFF000000u) & xm[k] & rowm;
             }
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
@@ -1120,7 +1129,7 @@ static u32 mean_magic(int k)
             const u32 d = (u32)(ks * ks), m = ((1u << 24) + d - 1) / d;
             bool ok = true;
             for (u32 sum = 0; sum <= 255u * d && ok; sum++)
-                ok = (uint64_t)sum * m <= 0xFFFFFFFFull && (u32)(((uint64_t)sum * m) >> 24) == sum / d;
+                ok = sum < (1u << 16) && m < (1u << 24) && (u32)(((uint64_t)sum * m) >> 24) == sum / d;
             t[ks] = ok ? m : 0u;
         }
         return t;

@@ -26,6 +26,13 @@ FILTERS = {
     "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
     "chain": lambda: ops.fused_chain(frames, 1.0, out),
 }
+import re  # noqa: E402
+m = re.fullmatch(r"(mean|gauss|median)(\d+)", name)
+if name not in FILTERS and m:     # any kernel size: mean11, gauss13, ...
+    k = int(m.group(2))
+    FILTERS[name] = {"mean": lambda: ops.mean_blur(frames, k, out),
+                     "gauss": lambda: ops.gaussian_blur(frames, k, 2.0, out),
+                     "median": lambda: ops.median_blur(frames, k, out)}[m.group(1)]
 for _ in range(reps):
     FILTERS[name]()
 torch.cuda.synchronize()

@@ -901,6 +901,87 @@ __global__ __launch_bounds__(256) void mean_generic_kernel(const u32* __restrict
     out[(i64)y * g.W + x - g.out_origin] = o;
 }
 
+// imageMeanBlur for kernel sizes 17..31, where the wave march's window no longer fits in registers:
+// one block per 64 x 16 output tile.  The tile and its border go to LDS (by flat index, so the
+// taps wrap from row to row like the reference's), then a row pass leaves k-sums per channel in
+// LDS -- (R,B) share a word, a row sum is at most 31*255 -- and a column pass adds k of those in
+// 32 bits; the division is (s * magic) >> 32 with magic = ceil(2^32 / k^2), exact for every
+// reachable s (checked on the host).
+constexpr int MT_W = 64, MT_H = 16;
+__global__ __launch_bounds__(256) void mean_tile_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                        const Geo g, int k, u32 magic)
+{
+    extern __shared__ u32 lds[];
+    const int r = k / 2;
+    const int PW = MT_W + 2 * r, PH = MT_H + 2 * r;
+    u32* pix = lds;                    // [PH][PW]
+    u32* sum_rb = pix + PH * PW;       // [PH][MT_W]
+    u32* sum_g = sum_rb + PH * MT_W;   // [PH][MT_W]
+    const int x0 = blockIdx.x * MT_W, y0 = g.y_begin + blockIdx.y * MT_H, frame = blockIdx.z;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    const int tid = threadIdx.x;
+
+    for (int idx = tid; idx < PH * PW; idx += 256) {
+        const int ty = idx / PW, tx = idx - ty * PW;
+        pix[idx] = tap_px(in, g, (i64)(y0 - r + ty) * g.W + (x0 - r + tx));
+    }
+    __syncthreads();
+    // row pass: a task is 8 consecutive outputs of one tile row, the first a full k-sum, the others
+    // by sliding (one tap in, one out)
+    for (int task = tid; task < PH * (MT_W / 8); task += 256) {
+        const int ty = task / (MT_W / 8), ox = (task % (MT_W / 8)) * 8;
+        const u32* row = pix + ty * PW + ox;
+        u32 rb = 0, gg = 0;
+        for (int t = 0; t < k; t++) {
+            const u32 p = row[t];
+            rb += p & 0x00ff00ffu;
+            gg += (p >> 8) & 0xffu;
+        }
+        sum_rb[ty * MT_W + ox] = rb;
+        sum_g[ty * MT_W + ox] = gg;
+#pragma unroll
+        for (int e = 1; e < 8; e++) {
+            const u32 a = row[k + e - 1], d = row[e - 1];
+            rb += (a & 0x00ff00ffu) - (d & 0x00ff00ffu);   // each half stays within [0, 31*255]: no borrow crosses
+            gg += ((a >> 8) & 0xffu) - ((d >> 8) & 0xffu);
+            sum_rb[ty * MT_W + ox + e] = rb;
+            sum_g[ty * MT_W + ox + e] = gg;
+        }
+    }
+    __syncthreads();
+    // column pass: a lane owns 4 vertically adjacent outputs of one column, again one full sum and three slides
+    {
+        const int ox = tid % MT_W, oy0 = (tid / MT_W) * (MT_H / 4);
+        const int x = x0 + ox;
+        u32 ar = 0, ab = 0, ag = 0;
+        for (int t = 0; t < k - 1; t++) {
+            const u32 rb = sum_rb[(oy0 + t) * MT_W + ox];
+            ar += rb & 0xffffu;
+            ab += rb >> 16;
+            ag += sum_g[(oy0 + t) * MT_W + ox];
+        }
+#pragma unroll
+        for (int e = 0; e < MT_H / 4; e++) {
+            const int oy = oy0 + e, y = y0 + oy;
+            const u32 rb = sum_rb[(oy + k - 1) * MT_W + ox];
+            ar += rb & 0xffffu;
+            ab += rb >> 16;
+            ag += sum_g[(oy + k - 1) * MT_W + ox];
+            if (x < g.W && y < g.y_end) {
+                u32 o = 0;
+                if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2)
+                    o = __umulhi(ar, magic) | (__umulhi(ag, magic) << 8) | (__umulhi(ab, magic) << 16) | 0xFF000000u;
+                out[(i64)y * g.W + x - g.out_origin] = o;
+            }
+            const u32 old = sum_rb[oy * MT_W + ox];
+            ar -= old & 0xffffu;
+            ab -= old >> 16;
+            ag -= sum_g[oy * MT_W + ox];
+        }
+    }
+}
+
 // ============================================================================ median 5x5
 // 13th smallest of the 25 flat taps per channel, alpha 255, same write set as the other stencils.
 // Wave march with one margin lane on each side (62 productive lanes, like the fused chain).
@@ -1137,6 +1218,22 @@ static u32 mean_magic(int k)
     return (k >= 0 && k < 16) ? table[k] : 0u;
 }
 
+// ceil(2^32 / k^2) for k = 17..31 when (s * m) >> 32 == s / k^2 for every s <= 255 k^2, else 0
+static u32 mean_magic32(int k)
+{
+    static const std::array<u32, 32> table = [] {
+        std::array<u32, 32> t{};
+        for (int ks = 17; ks <= 31; ks += 2) {
+            const uint64_t d = (uint64_t)ks * ks, m = ((1ull << 32) + d - 1) / d;
+            bool ok = m < (1ull << 32);
+            for (uint64_t sum = 0; sum <= 255u * d && ok; sum++) ok = ((sum * m) >> 32) == sum / d;
+            t[ks] = ok ? (u32)m : 0u;
+        }
+        return t;
+    }();
+    return (k >= 0 && k < 32) ? table[k] : 0u;
+}
+
 template <int R>
 static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic)
 {
@@ -1230,6 +1327,23 @@ int launch_filter(const FilterArgs& a)
     const bool direct_march = a.filter == MI_FILTER_GAUSSIAN_DIRECT && a.ksize >= 3 && a.ksize <= 7;
     const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT && !direct_march;
     const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15);
+    if (mean_generic && a.ksize >= 17 && a.ksize <= 31 && mean_magic32(a.ksize)) {
+        g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
+        const int r = a.ksize / 2;
+        const size_t lds = ((size_t)(MT_H + 2 * r) * (MT_W + 2 * r) + 2 * (size_t)(MT_H + 2 * r) * MT_W) * sizeof(u32);
+        const int tiles_y = (rows + MT_H - 1) / MT_H;
+        for (int f0 = 0; f0 < a.batch; f0 += 65535) {
+            const int nb = std::min(65535, a.batch - f0);
+            for (int t0 = 0; t0 < tiles_y; t0 += 65535) {
+                Geo gg = g;
+                gg.y_begin = a.y_begin + t0 * MT_H;
+                const dim3 grid((W + MT_W - 1) / MT_W, std::min(65535, tiles_y - t0), nb);
+                mean_tile_kernel<<<grid, 256, lds, a.stream>>>(in + (i64)f0 * in_frame, out + (i64)f0 * out_frame, gg,
+                                                              a.ksize, mean_magic32(a.ksize));
+            }
+        }
+        return hip_status(hipGetLastError(), "tiled mean kernel launch");
+    }
     if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {

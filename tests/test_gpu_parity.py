@@ -111,7 +111,7 @@ def test_mean3(dev, golden, w, h, kind):
     assert np.array_equal(host(ops.mean_blur(to_dev(img, dev), 3)), golden.meanblur(img, 3))
 
 
-@pytest.mark.parametrize("k", [1, 5, 7, 9, 11, 13, 15, 17, 31])
+@pytest.mark.parametrize("k", [1, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
 def test_mean_other_sizes(dev, golden, k):
     for (w, h) in ((67, 45), (256, 16), (5, 7), (300, 70), (512, 33)):
         img = S.synth_image(k, w, h)
@@ -188,7 +188,7 @@ STRIP_FILTERS = [
     (_lib.FILTER_GRAYSCALE, 0, 0.0), (_lib.FILTER_SOBEL, 3, 0.0), (_lib.FILTER_MEAN, 3, 0.0),
     (_lib.FILTER_MEDIAN, 3, 0.0), (_lib.FILTER_MEDIAN, 5, 0.0), (_lib.FILTER_GAUSSIAN, 5, 1.0),
     (_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_GAUSSIAN_DIRECT, 5, 1.0), (_lib.FILTER_MEAN, 7, 0.0),
-    (_lib.FILTER_MEAN, 15, 0.0), (_lib.FILTER_MEAN, 17, 0.0),
+    (_lib.FILTER_MEAN, 15, 0.0), (_lib.FILTER_MEAN, 17, 0.0), (_lib.FILTER_MEAN, 31, 0.0),
 ]
 
 

@@ -982,6 +982,62 @@ __global__ __launch_bounds__(256) void mean_tile_kernel(const u32* __restrict__ 
     }
 }
 
+// The direct (reference-order, bit-exact) Gaussian for kernel sizes 9..15: too many taps for the
+// wave march's registers, so one block per 64 x 16 output tile, with the tile and its border in
+// LDS like mean_tile_kernel.  A lane owns 4 horizontally adjacent outputs: every pixel of a window
+// row is read and widened once and feeds up to four accumulations, each of which still runs
+// ky outer, kx inner, sum = fmaf(pixel, weight, sum) from 0.
+template <int K>
+__global__ __launch_bounds__(256) void gauss_direct_tile_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                                const Geo g, const Weights2D wt)
+{
+    constexpr int R = K / 2, PW = MT_W + 2 * R, PH = MT_H + 2 * R;
+    __shared__ u32 pix[PH * PW];
+    __shared__ float wl[K * K];
+    const int x0 = blockIdx.x * MT_W, y0 = g.y_begin + blockIdx.y * MT_H, frame = blockIdx.z;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < PH * PW; idx += 256) {
+        const int ty = idx / PW, tx = idx - ty * PW;
+        pix[idx] = tap_px(in, g, (i64)(y0 - R + ty) * g.W + (x0 - R + tx));
+    }
+    for (int idx = tid; idx < K * K; idx += 256) wl[idx] = wt.w[idx];
+    __syncthreads();
+    const int gx = tid % (MT_W / 4), oy = tid / (MT_W / 4);
+    float acc[4][3] = {};
+    for (int ky = 0; ky < K; ky++) {
+        float w[K];
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) w[kx] = wl[ky * K + kx];
+        const u32* row = pix + (oy + ky) * PW + 4 * gx;
+#pragma unroll
+        for (int t = 0; t < K + 3; t++) {
+            const u32 p = row[t];
+            const float f[3] = {(float)(p & 0xffu), (float)((p >> 8) & 0xffu), (float)((p >> 16) & 0xffu)};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int kx = t - j;        // pixel t of the row is tap kx of output j
+                if (kx >= 0 && kx < K) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[j][c] = __builtin_fmaf(f[c], w[kx], acc[j][c]);
+                }
+            }
+        }
+    }
+    const int y = y0 + oy;
+    if (y >= g.y_end) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + 4 * gx + j;
+        if (x >= g.W) continue;
+        u32 o = 0;
+        if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2)
+            o = (u32)acc[j][0] | ((u32)acc[j][1] << 8) | ((u32)acc[j][2] << 16) | 0xFF000000u;
+        out[(i64)y * g.W + x - g.out_origin] = o;
+    }
+}
+
 // ============================================================================ median 5x5
 // 13th smallest of the 25 flat taps per channel, alpha 255, same write set as the other stencils.
 // Wave march with one margin lane on each side (62 productive lanes, like the fused chain).
@@ -1343,6 +1399,29 @@ int launch_filter(const FilterArgs& a)
             }
         }
         return hip_status(hipGetLastError(), "tiled mean kernel launch");
+    }
+    if (direct && a.ksize >= 9 && a.ksize <= 15) {
+        g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
+        Weights2D wt;
+        gaussian_kernel_2d(a.ksize, a.sigma, wt.w);
+        const int tiles_y = (rows + MT_H - 1) / MT_H;
+        for (int f0 = 0; f0 < a.batch; f0 += 65535) {
+            const int nb = std::min(65535, a.batch - f0);
+            for (int t0 = 0; t0 < tiles_y; t0 += 65535) {
+                Geo gg = g;
+                gg.y_begin = a.y_begin + t0 * MT_H;
+                const dim3 grid((W + MT_W - 1) / MT_W, std::min(65535, tiles_y - t0), nb);
+                const u32* pin = in + (i64)f0 * in_frame;
+                u32* pout = out + (i64)f0 * out_frame;
+                switch (a.ksize) {
+                case 9: gauss_direct_tile_kernel<9><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+                case 11: gauss_direct_tile_kernel<11><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+                case 13: gauss_direct_tile_kernel<13><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+                default: gauss_direct_tile_kernel<15><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+                }
+            }
+        }
+        return hip_status(hipGetLastError(), "tiled direct Gaussian kernel launch");
     }
     if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;

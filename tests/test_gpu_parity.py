@@ -155,9 +155,9 @@ def test_gaussian_separable_within_1_lsb(dev, golden, k, sigma):
     assert worst <= GAUSS_TOL
 
 
-@pytest.mark.parametrize("k,sigma", [(1, 0.5), (3, 7.0), (5, 1.0), (7, 1.5), (9, 2.0), (15, 2.5)])
+@pytest.mark.parametrize("k,sigma", [(1, 0.5), (3, 7.0), (5, 1.0), (7, 1.5), (9, 2.0), (11, 2.0), (13, 3.0), (15, 2.5)])
 def test_gaussian_direct_is_bit_exact(dev, golden, k, sigma):
-    for (w, h) in ((67, 45), (64, 48), (5, 7), (256, 16)):
+    for (w, h) in ((67, 45), (64, 48), (5, 7), (256, 16), (130, 35)):
         img = S.synth_image(100 + k, w, h)
         got = host(ops.gaussian_blur(to_dev(img, dev), k, sigma, direct=True))
         assert np.array_equal(got, golden.gaussian(img, k, sigma))
@@ -189,6 +189,7 @@ STRIP_FILTERS = [
     (_lib.FILTER_MEDIAN, 3, 0.0), (_lib.FILTER_MEDIAN, 5, 0.0), (_lib.FILTER_GAUSSIAN, 5, 1.0),
     (_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_GAUSSIAN_DIRECT, 5, 1.0), (_lib.FILTER_MEAN, 7, 0.0),
     (_lib.FILTER_MEAN, 15, 0.0), (_lib.FILTER_MEAN, 17, 0.0), (_lib.FILTER_MEAN, 31, 0.0),
+    (_lib.FILTER_GAUSSIAN_DIRECT, 9, 2.0),
 ]
 
 

@@ -55,14 +55,15 @@ report(f"Sobel ({C})", ":255-285", px, 8, lambda: ops.sobel(fr, out))
 report(f"mean 3x3 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 3, out))
 report(f"mean 7x7 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 7, out), 20)
 report(f"mean 15x15 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 15, out), 20)
-report(f"mean 17x17, generic ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 3, "one lane per pixel (sizes above 15)")
+report(f"mean 17x17, LDS tiles ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 10, "sizes 17..31: tile + sliding sums in LDS")
+report(f"mean 31x31, LDS tiles ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 10, "sizes 17..31")
 report(f"median 3x3 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 3, out))
 report(f"median 5x5 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 5, out), 20, "VALU-bound")
 for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)):
     report(f"Gaussian {k}x{k} sigma {s}, separable ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out), 20)
 for k, s in ((3, 7.0), (5, 1.0), (7, 1.5)):
     report(f"Gaussian {k}x{k}, direct = the reference's summation order, bit-exact ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out, direct=True), 10, "VALU-bound: k*k fma per pixel and channel")
-report(f"Gaussian 9x9, direct, generic kernel ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 9, 2.0, out, direct=True), 3, "one lane per pixel (sizes above 7)")
+report(f"Gaussian 9x9, direct, LDS tiles ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 9, 2.0, out, direct=True), 10, "VALU-bound: 243 fma per pixel")
 report(f"fused chain gray>gauss5>median3>Sobel ({C})", "C2 chain", px, 8, lambda: ops.fused_chain(fr, 1.0, out), None, "the four kernels move 32 B/px")
 bufs = [torch.empty_like(fr) for _ in range(3)] + [out]
 report(f"the same chain as four kernels ({C})", "C2 chain", px, 32, lambda: ops.filter_chain(fr, bufs))

@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(256) void gauss_direct_tile_kernel(const u32* __res
     __syncthreads();
     const int gx = tid % (MT_W / 4), oy = tid / (MT_W / 4);
     float acc[4][3] = {};
+#pragma unroll 1   // unrolled, all K*K weights become live at once and occupancy collapses
     for (int ky = 0; ky < K; ky++) {
         float w[K];
 #pragma unroll

@@ -75,5 +75,5 @@ def build_demo(force=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
     print(build_demo(force="--force" in sys.argv))

@@ -72,12 +72,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # MI_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks (ranks share devices,
+    # the collectives go over the CPU); the real run is one rank per GPU over RCCL
+    backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch
     # frames [rank*B, (rank+1)*B) of the synthetic stream with seed 2
@@ -135,7 +143,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -468,14 +468,15 @@ int mi_host_release(void) { return host_release(); }
 
 // imageFFTImageGenerate's scaffold (imageTools.cu:633-791): u8 -> three complex planes -> forward
 // transform -> `edit` on each spectrum -> inverse -> /N, imaginary part dropped -> u8.
+// `rows` x `cols` is the geometry the transforms see (rows * cols == w * h).
 extern "C++" template <class Edit>
-static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edit edit)
+static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int rows, int cols, Edit edit)
 {
     int rc = check_image(in, out, w, h, 1);
     if (rc) return rc;
     const size_t n = (size_t)w * h;
     size_t ws_bytes = 0;
-    rc = mi_fft2d_workspace_bytes(h, w, &ws_bytes);
+    rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
     if (rc) return rc;
     // one cached device buffer: the image, three planes, three planes of spectrum (the transforms run out
     // of place, where tall planes take the fast split column pass), the chirp-z workspace
@@ -492,9 +493,9 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edi
     hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = mi_u8_to_complex_dev(d_img, pl, pl + n * 8, pl + 2 * n * 8, w, h, nullptr);
-        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl, spec, h, w, 3, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
+        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl, spec, rows, cols, 3, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
         for (int c = 0; c < 3 && rc == MI_OK; c++) rc = edit(spec + c * n * 8);
-        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(spec, pl, h, w, 3, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
+        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(spec, pl, rows, cols, 3, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
         for (int c = 0; c < 3 && rc == MI_OK; c++) rc = mi_normalize_zero_imag_dev(pl + c * n * 8, w, h, nullptr);
         if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
@@ -505,7 +506,11 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, Edi
 int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)
 {
     if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
-    return spectral_roundtrip(in, out, w, h, [&](void* plane) {
+    // The reference plans its transform as cufftPlan2d(&plan, width, height, ...) (imageTools.cu:688), and
+    // cufftPlan2d's first size is the slowest-varying dimension: the buffer is transformed as `width` rows
+    // of `height` points, while the shift and the filter index it as `height` rows of `width`.  Square
+    // images cannot tell; the reference's own 675x900 sample output is reproduced only this way.
+    return spectral_roundtrip(in, out, w, h, /*rows=*/w, /*cols=*/h, [&](void* plane) {
         int rc = mi_fftshift_dev(plane, w, h, nullptr);
         if (rc == MI_OK) rc = mi_highpass_dev(plane, w, h, cutoff, nullptr);
         if (rc == MI_OK) rc = mi_fftshift_dev(plane, w, h, nullptr);
@@ -524,7 +529,7 @@ int mi_compress_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float keep_f
     if (!(keep_fraction > 0.0f) || !(keep_fraction <= 1.0f))
         return fail(MI_ERR_INVALID_ARG, "keep_fraction must be in (0, 1] (got %g)", (double)keep_fraction);
     const size_t n = (size_t)w * h;
-    return spectral_roundtrip(in, out, w, h, [&](void* plane) {
+    return spectral_roundtrip(in, out, w, h, /*rows=*/h, /*cols=*/w, [&](void* plane) {
         return spectrum_keep_top(plane, n, keep_count(n, keep_fraction), nullptr);
     });
 }

@@ -209,7 +209,11 @@ int mi_run_ops_chunked_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const
                             int n_ops, int chunk_rows);
 int mi_host_release(void);
 /* imageFFTImageGenerate (imageTools.cu:633-791) without its debug means; cutoff is the
- * reference's hard-coded 10.0f (:716). */
+ * reference's hard-coded 10.0f (:716).  The transforms use the reference's plan geometry,
+ * cufftPlan2d(&plan, width, height, ...) (:688): the buffer is transformed as `w` rows of `h`
+ * points while the shift and the filter index it as `h` rows of `w` -- the same thing for a
+ * square image, and what reproduces the reference's own sample output for the 675x900 one
+ * (tests/golden/).  Sizes: w, h in [2, 4096], or powers of two up to 8192. */
 int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);
 /* compressImage (declared at kernels/imageTools.h:17 and commented out at main.cpp:44, never
  * defined upstream; defined by this library on the round-trip scaffold of imageFFTImageGenerate):
@@ -219,7 +223,7 @@ int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cu
 #define MI_COMPRESS_DEFAULT_KEEP 0.10f
 int mi_compress_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float keep_fraction);
 /* The selection step of mi_compress_u8x4 on a device spectrum of n complex values, in place.
- * Blocking (the threshold search reads two histograms back to the host). */
+ * Blocking (the threshold search reads three histograms back to the host). */
 int mi_spectrum_keep_top_dev(void *d_data, size_t n, size_t keep, void *stream);
 /* bool test() (declared at kernels/imageTools.h:19, never defined upstream): the library's
  * self-test -- known-answer checks of every filter, the transforms and the host pipeline on

@@ -315,60 +315,75 @@ void gold_u8_to_complex(const uint8_t *in, float *red, float *green, float *blue
     }
 }
 
-/* 1-D DFT in double: radix-2 for powers of two, the O(n^2) definition otherwise.
- * sign = -1 forward, +1 inverse, unnormalised -- cuFFT's convention (imageTools.cu:690,741). */
-static void dft1d(double *re, double *im, int n, int stride, int sign, double *tr, double *ti)
+/* Mixed-radix decimation in time for any n: n = p * m with p the smallest prime factor; the p
+ * interleaved sub-sequences are transformed recursively and combined by the definition,
+ *   X[k + m q] = sum_r W_n^(r (k + m q)) Y_r[k],   W_n = exp(sign * 2 pi i / n),
+ * so a prime length is the O(n^2) definition itself.  (wr, wi)[j] = W_N^j for the top-level N;
+ * a sub-transform of length n uses every (N/n)-th entry.  x is read with `stride`, y is dense;
+ * `scratch` holds 2n doubles per recursion level (2N in total is enough: n + n/p + ... < 2n). */
+static void dft_rec(const double *xr, const double *xi, int n, int stride, double *yr, double *yi,
+                    const double *wr, const double *wi, int N, double *scratch)
 {
-    if ((n & (n - 1)) == 0) {
-        for (int i = 0; i < n; i++) { tr[i] = re[(int64_t)i * stride]; ti[i] = im[(int64_t)i * stride]; }
-        for (int i = 1, j = 0; i < n; i++) {           /* bit reversal */
-            int bit = n >> 1;
-            for (; j & bit; bit >>= 1) j ^= bit;
-            j ^= bit;
-            if (i < j) { double a = tr[i]; tr[i] = tr[j]; tr[j] = a; a = ti[i]; ti[i] = ti[j]; ti[j] = a; }
-        }
-        for (int len = 2; len <= n; len <<= 1) {
-            double ang = sign * 2.0 * M_PI / len;
-            for (int i = 0; i < n; i += len)
-                for (int j = 0; j < len / 2; j++) {
-                    double wr = cos(ang * j), wi = sin(ang * j);
-                    double ur = tr[i + j], ui = ti[i + j];
-                    double vr = tr[i + j + len / 2] * wr - ti[i + j + len / 2] * wi;
-                    double vi = tr[i + j + len / 2] * wi + ti[i + j + len / 2] * wr;
-                    tr[i + j] = ur + vr; ti[i + j] = ui + vi;
-                    tr[i + j + len / 2] = ur - vr; ti[i + j + len / 2] = ui - vi;
-                }
-        }
-        for (int i = 0; i < n; i++) { re[(int64_t)i * stride] = tr[i]; im[(int64_t)i * stride] = ti[i]; }
+    if (n == 1) { yr[0] = xr[0]; yi[0] = xi[0]; return; }
+    int p = n;
+    for (int f = 2; (int64_t)f * f <= n; f++) if (n % f == 0) { p = f; break; }
+    int m = n / p, step = N / n;
+    double *sr = scratch, *si = scratch + n;           /* Y_r[k] at [r*m + k] */
+    if (p == n) {
+        for (int r = 0; r < n; r++) { sr[r] = xr[(int64_t)r * stride]; si[r] = xi[(int64_t)r * stride]; }
     } else {
-        for (int k = 0; k < n; k++) {
-            double sr = 0, si = 0;
-            for (int t = 0; t < n; t++) {
-                double ang = sign * 2.0 * M_PI * (double)(((int64_t)k * t) % n) / n;
-                double wr = cos(ang), wi = sin(ang);
-                double xr = re[(int64_t)t * stride], xi = im[(int64_t)t * stride];
-                sr += xr * wr - xi * wi; si += xr * wi + xi * wr;
-            }
-            tr[k] = sr; ti[k] = si;
-        }
-        for (int i = 0; i < n; i++) { re[(int64_t)i * stride] = tr[i]; im[(int64_t)i * stride] = ti[i]; }
+        for (int r = 0; r < p; r++)
+            dft_rec(xr + (int64_t)r * stride, xi + (int64_t)r * stride, m, stride * p, sr + r * m, si + r * m,
+                    wr, wi, N, scratch + 2 * n);
     }
+    for (int q = 0; q < p; q++)
+        for (int k = 0; k < m; k++) {
+            double ar = 0, ai = 0;
+            int64_t idx = k + (int64_t)m * q;
+            for (int r = 0; r < p; r++) {
+                int64_t e = ((int64_t)r * idx) % n * step;
+                double cr = wr[e], ci = wi[e], vr = sr[r * m + k], vi = si[r * m + k];
+                ar += vr * cr - vi * ci; ai += vr * ci + vi * cr;
+            }
+            yr[idx] = ar; yi[idx] = ai;
+        }
+}
+
+/* 1-D DFT in double, in place on a strided line.  sign = -1 forward, +1 inverse, unnormalised --
+ * cuFFT's convention (imageTools.cu:690,741).  tw = 2n doubles of twiddles for this n and sign,
+ * work = 6n doubles. */
+static void dft1d(double *re, double *im, int n, int stride, const double *tw, double *work)
+{
+    double *yr = work, *yi = work + n;
+    dft_rec(re, im, n, stride, yr, yi, tw, tw + n, n, work + 2 * n);
+    for (int i = 0; i < n; i++) { re[(int64_t)i * stride] = yr[i]; im[(int64_t)i * stride] = yi[i]; }
+}
+
+static double *dft_twiddles(int n, int sign)
+{
+    double *tw = (double *)malloc(sizeof(double) * 2 * n);
+    for (int j = 0; j < n; j++) {
+        double ang = sign * 2.0 * M_PI * (double)j / n;
+        tw[j] = cos(ang); tw[n + j] = sin(ang);
+    }
+    return tw;
 }
 
 /* 2-D complex DFT of `rows` rows of `cols` elements, interleaved (re,im) double, in place.
- * The mathematical 2-D DFT; the reference's cufftPlan2d(width,height) (imageTools.cu:688)
- * equals it for square images and is a bug otherwise. */
+ * The caller chooses the geometry: the reference's cufftPlan2d(width,height) (imageTools.cu:688)
+ * is rows = width, cols = height (see gold_fft_highpass_image). */
 void gold_fft2d_f64(double *data, int rows, int cols, int sign)
 {
     int64_t n = (int64_t)rows * cols;
     int m = rows > cols ? rows : cols;
     double *re = (double *)malloc(sizeof(double) * n), *im = (double *)malloc(sizeof(double) * n);
-    double *tr = (double *)malloc(sizeof(double) * m), *ti = (double *)malloc(sizeof(double) * m);
+    double *work = (double *)malloc(sizeof(double) * 6 * m);
+    double *twc = dft_twiddles(cols, sign), *twr = dft_twiddles(rows, sign);
     for (int64_t i = 0; i < n; i++) { re[i] = data[2 * i]; im[i] = data[2 * i + 1]; }
-    for (int y = 0; y < rows; y++) dft1d(re + (int64_t)y * cols, im + (int64_t)y * cols, cols, 1, sign, tr, ti);
-    for (int x = 0; x < cols; x++) dft1d(re + x, im + x, rows, cols, sign, tr, ti);
+    for (int y = 0; y < rows; y++) dft1d(re + (int64_t)y * cols, im + (int64_t)y * cols, cols, 1, twc, work);
+    for (int x = 0; x < cols; x++) dft1d(re + x, im + x, rows, cols, twr, work);
     for (int64_t i = 0; i < n; i++) { data[2 * i] = re[i]; data[2 * i + 1] = im[i]; }
-    free(re); free(im); free(tr); free(ti);
+    free(re); free(im); free(work); free(twc); free(twr);
 }
 
 /* fp32 in / fp32 out wrapper: the transform itself is evaluated in double and rounded once. */
@@ -447,6 +462,12 @@ void gold_complex_to_u8(const float *red, const float *green, const float *blue,
 
 /* imageFFTImageGenerate, imageTools.cu:633-791, minus the debug means: per channel
  * u8 -> complex -> fft2d -> shift -> high-pass(cutoff) -> shift -> ifft2d -> /N, im=0 -> u8.
+ * The plan is cufftPlan2d(&plan, width, height, CUFFT_C2C) (:688), and cufftPlan2d's first size
+ * is the slowest-varying dimension: the transform treats the W*H buffer as `width` rows of `height`
+ * points, while fftShift and highpassFilter index it as `height` rows of `width` (:535, :569-572).
+ * For a square image the two agree; for any other it is this reshaped transform that the
+ * reference computes, and its own sample output (image/output.jpg, made from the 675x900
+ * image/lord.jpeg) is reproduced only this way (tests/test_oracle.py, tests/test_gpu_golden.py).
  * `real_out` (3 planes of W*H floats, may be NULL) receives the real parts before the cast:
  * that float image is what the device path is compared against (rel-L2). */
 void gold_fft_highpass_image(const uint8_t *in, uint8_t *out, float *real_out, int w, int h,
@@ -457,11 +478,11 @@ void gold_fft_highpass_image(const uint8_t *in, uint8_t *out, float *real_out, i
     for (int c = 0; c < 3; c++) pl[c] = (float *)malloc(sizeof(float) * 2 * n);
     gold_u8_to_complex(in, pl[0], pl[1], pl[2], n);
     for (int c = 0; c < 3; c++) {
-        gold_fft2d_c2c(pl[c], pl[c], h, w, -1);
+        gold_fft2d_c2c(pl[c], pl[c], w, h, -1);     /* rows = width, cols = height: see above */
         gold_fftshift(pl[c], w, h);
         gold_highpass(pl[c], w, h, cutoff);
         gold_fftshift(pl[c], w, h);
-        gold_fft2d_c2c(pl[c], pl[c], h, w, +1);
+        gold_fft2d_c2c(pl[c], pl[c], w, h, +1);
         gold_normalize_zero_imag(pl[c], w, h);
         if (real_out)
             for (int64_t i = 0; i < n; i++) real_out[c * n + i] = pl[c][2 * i];

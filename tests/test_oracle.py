@@ -6,6 +6,7 @@ and cannot be built here (CUDA only), so these checks are all that pins the orac
 "parity unpinned" in the sense of the task statement.  CPU only.
 """
 import math
+import os
 from fractions import Fraction
 
 import numpy as np
@@ -404,3 +405,22 @@ def test_oracle_reproduces_committed_vectors(golden):
         assert np.abs(golden.compress_image(img, 0.10).astype(int) - vec[f"{name}.compress_keep10"]).max() <= 1
     for k, s in ((3, 7.0), (5, 1.0), (15, 2.5)):
         assert np.array_equal(golden.gaussian_kernel(k, s), vec[f"gaussian_kernel_{k}"])
+
+
+def test_fft_highpass_reproduces_the_upstream_sample_output(golden):
+    """The one output the reference's authors left behind: image/output.jpg (a 675x900 RGBA PNG), made by
+    their main.cpp (imageFFTImageGenerate, cutoff 10) from image/lord.jpeg on their GPU; both files are
+    committed under tests/golden/ as data.  The oracle must reproduce it.  The input is decoded with Pillow
+    here, upstream used stb_image (the two JPEG decoders differ by an LSB on some pixels), so the bar is
+    'almost every byte identical, none far off': measured 98.4 % identical, 99.9 % within 1, max 3.
+    With the mathematically correct 2-D geometry (rows = height) instead of the reference's
+    cufftPlan2d(width, height), only 31 % of the bytes agree and the mean error is 16 levels."""
+    Image = pytest.importorskip("PIL.Image")
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(here, "lord.jpeg")).convert("RGBA")))
+    want = np.asarray(Image.open(os.path.join(here, "upstream_output_of_lord.png")))
+    assert img.shape == (900, 675, 4) and want.shape == (900, 675, 4)
+    got, _ = golden.fft_highpass_image(img, 10.0)
+    assert np.array_equal(got[..., 3], want[..., 3])
+    d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
+    assert (d == 0).mean() >= 0.97 and (d <= 1).mean() >= 0.995 and d.max() <= 4

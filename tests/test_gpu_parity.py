@@ -175,6 +175,9 @@ def test_batch_equals_per_frame(dev, golden):
         ("median3", lambda t: ops.median_blur(t, 3), lambda x: golden.medianblur(x, 3)),
         ("median5", lambda t: ops.median_blur(t, 5), lambda x: golden.medianblur(x, 5)),
         ("gauss_direct", lambda t: ops.gaussian_blur(t, 5, 1.0, direct=True), lambda x: golden.gaussian(x, 5, 1.0)),
+        ("mean15", lambda t: ops.mean_blur(t, 15), lambda x: golden.meanblur(x, 15)),
+        ("mean19_tiles", lambda t: ops.mean_blur(t, 19), lambda x: golden.meanblur(x, 19)),
+        ("gauss_direct11_tiles", lambda t: ops.gaussian_blur(t, 11, 2.0, direct=True), lambda x: golden.gaussian(x, 11, 2.0)),
     ):
         out = host(fn(d))
         for f in range(b):

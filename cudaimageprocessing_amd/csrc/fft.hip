@@ -619,13 +619,77 @@ __global__ __launch_bounds__(256) void blue_post_kernel(const c2* __restrict__ p
     dst[l * dst_stride + k] = v;
 }
 
+// The whole chirp-z transform of a line in one kernel: the line never leaves LDS between the chirp
+// multiply, the m-point transform, the multiplication by the transformed chirp, the inverse
+// m-point transform and the final chirp multiply, so a pass reads n points and writes n points per
+// line where the five separate kernels above move about 8 m.  Same operations in the same order
+// as those kernels (which remain for m < 16): the results are bit-identical.
+// LPB lines per block iteration, M/16 lanes per line, 16 points per lane (point i = t + (M/16) k).
+template <int M, int LPB>
+__global__ __launch_bounds__((M / 16) * LPB) void blue_lines_kernel(const c2* __restrict__ src, i64 src_stride,
+                                                                    c2* __restrict__ dst, i64 dst_stride, int nlines,
+                                                                    int n, const c2* __restrict__ chirp,
+                                                                    const c2* __restrict__ bhat, int inverse)
+{
+    constexpr int T = M / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    c2* lds = reinterpret_cast<c2*>(lds_raw);
+    const int tid = threadIdx.x, lin = tid / T, t = tid % T;
+    c2* line = lds + lin * (M + M / 16);
+    c2* tw = lds + LPB * (M + M / 16);
+    fill_twiddles<M>(tw, tid, T * LPB);
+    __syncthreads();
+    const float inv_m = 1.0f / (float)M;
+    // the trip count is block-uniform: the barriers inside fft_line are safe
+    for (i64 L0 = (i64)blockIdx.x * LPB; L0 < nlines; L0 += (i64)gridDim.x * LPB) {
+        const i64 l = L0 + lin;
+        const bool active = l < nlines;
+        const c2* x = src + l * src_stride;
+        c2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = t + T * k;
+            c2 a{0.f, 0.f};
+            if (active && i < n) {
+                a = x[i];
+                if (inverse) a.y = -a.y;
+                a = cmul(a, chirp[i]);
+            }
+            v[k] = a;
+        }
+        fft_line<M>(v, line, tw, t);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            v[k] = cmul(v[k], bhat[t + T * k]);
+            v[k].y = -v[k].y;                      // inverse transform = conj, forward transform, conj
+        }
+        fft_line<M>(v, line, tw, t);
+        c2* y = dst + l * dst_stride;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = t + T * k;
+            if (active && i < n) {
+                c2 r = v[k];
+                r.y = -r.y;
+                r = cmul(r, chirp[i]);
+                r.x *= inv_m; r.y *= inv_m;
+                if (inverse) r.y = -r.y;
+                y[i] = r;
+            }
+        }
+    }
+}
+
 // dst (cols x rows) = transpose of src (rows x cols); 32x32 tiles through LDS
+// (blockIdx.z = plane of a batch of back-to-back planes)
 __global__ __launch_bounds__(256) void transpose_c2_kernel(const c2* __restrict__ src, c2* __restrict__ dst,
                                                            int rows, int cols)
 {
     __shared__ c2 tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    src += (i64)blockIdx.z * rows * cols;
+    dst += (i64)blockIdx.z * rows * cols;
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         const int x = x0 + tx, y = y0 + ty + j;
@@ -672,6 +736,26 @@ static int pow2_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, in
 
 struct BlueTables { const c2* chirp; const c2* bhat; int m; };
 
+template <int M, int LPB>
+static int launch_blue_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int nlines, int n, int inverse,
+                             const BlueTables& t, hipStream_t s)
+{
+    constexpr int threads = (M / 16) * LPB;
+    constexpr size_t lds = ((size_t)LPB * (M + M / 16) + Plan<M>::tw_total) * sizeof(c2);
+    static_assert(lds <= 160 * 1024, "a block's lines and twiddle tables must fit the CU's LDS");
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        if (lds > 64 * 1024)
+            attr_err = hipFuncSetAttribute((const void*)blue_lines_kernel<M, LPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
+    const i64 blocks = ((i64)nlines + LPB - 1) / LPB;
+    const int grid = (int)std::min<i64>(blocks, 256 * 8);
+    blue_lines_kernel<M, LPB><<<grid, threads, lds, s>>>(src, src_stride, dst, dst_stride, nlines, n, t.chirp, t.bhat, inverse);
+    return hip_status(hipGetLastError(), "chirp-z kernel launch");
+}
+
 // Any n: lines as above; `pad` holds nlines * m points when n is not a power of two.
 static int any_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int nlines, int n, int dir,
                      const BlueTables& t, c2* pad, hipStream_t s)
@@ -679,6 +763,21 @@ static int any_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int
     if (t.m == 0) return pow2_lines(src, src_stride, dst, dst_stride, nlines, n, dir, s);
     const int m_log2 = __builtin_ctz(t.m);
     const int inverse = dir > 0;
+    if (env_int("MI_FFT_FUSED_CHIRPZ", 1)) {
+        switch (t.m) {     // lines per block as in launch_pass's row pass
+        case 16: return launch_blue_lines<16, 64>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 32: return launch_blue_lines<32, 64>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 64: return launch_blue_lines<64, 64>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 128: return launch_blue_lines<128, 32>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 256: return launch_blue_lines<256, 16>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 512: return launch_blue_lines<512, 8>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 1024: return launch_blue_lines<1024, 4>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 2048: return launch_blue_lines<2048, 2>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 4096: return launch_blue_lines<4096, 1>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 8192: return launch_blue_lines<8192, 1>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        default: break;    // m = 8 (n = 3): the separate kernels below
+        }
+    }
     int grid = 0;
     int rc = grid_for((i64)nlines * t.m, &grid);
     if (rc) return rc;
@@ -743,15 +842,21 @@ int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, i
     rc = make_tables(tc, cols);
     if (rc == MI_OK) rc = make_tables(tr, rows);
     if (rc) return rc;
-    const dim3 tgrid_fwd((cols + 31) / 32, (rows + 31) / 32), tgrid_back((rows + 31) / 32, (cols + 31) / 32);
     const i64 plane = (i64)rows * cols;
-    for (int b = 0; b < batch; b++) {
+    // Planes go through in groups: the transposed copies of a group live in the workspace's plane and
+    // (when the fused kernels run, which need no padded lines) its padded-line area -- at least three
+    // planes together.  With the separate kernels (MI_FFT_FUSED_CHIRPZ=0, or m = 8) one plane at a time.
+    const bool fused = env_int("MI_FFT_FUSED_CHIRPZ", 1) && (L.mc == 0 || L.mc >= 16) && (L.mr == 0 || L.mr >= 16);
+    const int group = fused ? (int)std::min<i64>(std::min<i64>(batch, 65535), std::max<i64>(1, (L.plane_t + L.pad) / plane)) : 1;
+    for (int b = 0; b < batch; b += group) {
+        const int nb = std::min(group, batch - b);
         const c2* pin = (const c2*)in + b * plane;
         c2* pout = (c2*)out + b * plane;
-        rc = any_lines(pin, cols, pout, cols, rows, cols, dir, tc, pad, s);            // rows
+        const dim3 tgrid_fwd((cols + 31) / 32, (rows + 31) / 32, nb), tgrid_back((rows + 31) / 32, (cols + 31) / 32, nb);
+        rc = any_lines(pin, cols, pout, cols, rows * nb, cols, dir, tc, pad, s);            // rows (planes are back to back)
         if (rc) return rc;
         transpose_c2_kernel<<<tgrid_fwd, 256, 0, s>>>(pout, plane_t, rows, cols);
-        rc = any_lines(plane_t, rows, plane_t, rows, cols, rows, dir, tr, pad, s);     // columns, as rows of the transpose
+        rc = any_lines(plane_t, rows, plane_t, rows, cols * nb, rows, dir, tr, pad, s);     // columns, as rows of the transposes
         if (rc) return rc;
         transpose_c2_kernel<<<tgrid_back, 256, 0, s>>>(plane_t, pout, cols, rows);
         rc = hip_status(hipGetLastError(), "transpose kernel launch");

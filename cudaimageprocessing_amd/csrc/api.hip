@@ -494,10 +494,10 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int
     if (e == hipSuccess) {
         rc = mi_u8_to_complex_dev(d_img, pl, pl + n * 8, pl + 2 * n * 8, w, h, nullptr);
         if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl, spec, rows, cols, 3, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
-        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = edit(spec + c * n * 8);
+        if (rc == MI_OK) rc = edit(spec);                       // the three spectra, back to back
         if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(spec, pl, rows, cols, 3, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
-        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = mi_normalize_zero_imag_dev(pl + c * n * 8, w, h, nullptr);
-        if (rc == MI_OK) rc = mi_complex_to_u8_dev(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
+        // NormalizeAndZeroImaginary and ComplexRGBToUchar in one pass
+        if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
     }
     return rc ? rc : hip_status(e, "spectral round trip");
@@ -510,11 +510,9 @@ int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cu
     // cufftPlan2d's first size is the slowest-varying dimension: the buffer is transformed as `width` rows
     // of `height` points, while the shift and the filter index it as `height` rows of `width`.  Square
     // images cannot tell; the reference's own 675x900 sample output is reproduced only this way.
-    return spectral_roundtrip(in, out, w, h, /*rows=*/w, /*cols=*/h, [&](void* plane) {
-        int rc = mi_fftshift_dev(plane, w, h, nullptr);
-        if (rc == MI_OK) rc = mi_highpass_dev(plane, w, h, cutoff, nullptr);
-        if (rc == MI_OK) rc = mi_fftshift_dev(plane, w, h, nullptr);
-        return rc;
+    return spectral_roundtrip(in, out, w, h, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
+        // shift, filter, shift (imageTools.cu:704-737) as one pass over the three planes
+        return launch_highpass_unshifted(spectra, w, h, 3, cutoff, nullptr);
     });
 }
 
@@ -529,8 +527,10 @@ int mi_compress_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float keep_f
     if (!(keep_fraction > 0.0f) || !(keep_fraction <= 1.0f))
         return fail(MI_ERR_INVALID_ARG, "keep_fraction must be in (0, 1] (got %g)", (double)keep_fraction);
     const size_t n = (size_t)w * h;
-    return spectral_roundtrip(in, out, w, h, /*rows=*/h, /*cols=*/w, [&](void* plane) {
-        return spectrum_keep_top(plane, n, keep_count(n, keep_fraction), nullptr);
+    return spectral_roundtrip(in, out, w, h, /*rows=*/h, /*cols=*/w, [&](char* spectra) {
+        int rc = MI_OK;
+        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = spectrum_keep_top(spectra + c * n * 8, n, keep_count(n, keep_fraction), nullptr);
+        return rc;
     });
 }
 

@@ -82,6 +82,44 @@ __global__ __launch_bounds__(256) void highpass_kernel(f32x2v* __restrict__ d, i
     }
 }
 
+// fftShift -> highpassFilter -> fftShift (imageTools.cu:704-737) as one pass over `planes` back-to-back
+// planes: the shift is an involution that swaps pairs of elements, so the three steps multiply the
+// element at p by the gain evaluated at the position p is swapped with (at p itself for the middle
+// row / column of an odd size, which the shift leaves alone).  Same float expression for the gain,
+// one multiplication per component: bit-identical to the three kernels.
+__global__ __launch_bounds__(256) void highpass_unshifted_kernel(f32x2v* __restrict__ d, int w, int h,
+                                                                 float cutoff, i64 total)
+{
+    const int hw = w / 2, hh = h / 2;
+    const i64 plane = (i64)w * h, stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const i64 p = i % plane;
+        int y = (int)(p / w), x = (int)(p % w);
+        if (x < 2 * hw && y < 2 * hh) {
+            x = x < hw ? x + hw : x - hw;
+            y = y < hh ? y + hh : y - hh;
+        }
+        const float cx = (float)x - (float)w / 2.0f;
+        const float cy = (float)y - (float)h / 2.0f;
+        const float distance = sqrtf(cx * cx + cy * cy);
+        const float gain = 1.0f - expf(-(distance * distance) / (2.0f * cutoff * cutoff));
+        f32x2v v = d[i];
+        v.x *= gain; v.y *= gain;
+        d[i] = v;
+    }
+}
+
+// NormalizeAndZeroImaginary + ComplexRGBToUchar (imageTools.cu:551-562, :517-527) in one pass.
+__global__ __launch_bounds__(256) void complex_to_u8_normalized_kernel(const f32x2v* __restrict__ r,
+                                                                       const f32x2v* __restrict__ g,
+                                                                       const f32x2v* __restrict__ b,
+                                                                       u32* __restrict__ out, i64 n, float div)
+{
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = sat_u8(r[i].x / div) | (sat_u8(g[i].x / div) << 8) | (sat_u8(b[i].x / div) << 16) | 0xFF000000u;
+}
+
 // NormalizeAndZeroImaginary, imageTools.cu:551-562: re /= (float)(W*H), im = 0.
 __global__ __launch_bounds__(256) void normalize_zero_imag_kernel(f32x2v* __restrict__ d, i64 n,
                                                                   float div)
@@ -197,6 +235,21 @@ int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s)
 {
     highpass_kernel<<<flat_grid((i64)w * h), 256, 0, s>>>((f32x2v*)d, w, h, cutoff);
     return hip_status(hipGetLastError(), "highpass launch");
+}
+
+int launch_highpass_unshifted(void* d, int w, int h, int planes, float cutoff, hipStream_t s)
+{
+    const i64 total = (i64)w * h * planes;
+    highpass_unshifted_kernel<<<flat_grid(total), 256, 0, s>>>((f32x2v*)d, w, h, cutoff, total);
+    return hip_status(hipGetLastError(), "highpass launch");
+}
+
+int launch_complex_to_u8_normalized(const void* r, const void* g, const void* b, void* out, int w, int h, hipStream_t s)
+{
+    const i64 n = (i64)w * h;
+    complex_to_u8_normalized_kernel<<<flat_grid(n), 256, 0, s>>>((const f32x2v*)r, (const f32x2v*)g, (const f32x2v*)b,
+                                                                 (u32*)out, n, (float)(w * h));
+    return hip_status(hipGetLastError(), "complex_to_u8 launch");
 }
 
 int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s)

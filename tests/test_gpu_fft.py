@@ -216,6 +216,27 @@ def test_minmax_and_normalize(dev, golden):
     assert ops.minmax(neg).cpu().numpy().tolist() == [-3.0, -1.0]
 
 
+@pytest.mark.parametrize("w,h", [(67, 45), (64, 48), (33, 40), (128, 128), (5, 9)])
+def test_host_tier_highpass_equals_the_device_tier_steps(dev, w, h):
+    """mi_fft_highpass_u8x4 fuses shift/filter/shift into one pass over the three planes and the
+    normalisation into the final cast: byte for byte what the reference's sequence of kernels
+    (imageTools.cu:659-781), run step by step through the device tier, produces -- odd sizes,
+    whose middle row and column the shift leaves alone, included."""
+    img = S.synth_image(w * 131 + h, w, h)
+    out = np.empty_like(img)
+    ops.imageFFTImageGenerate(out, img, w, h)
+    planes = ops.u8_to_complex(torch.from_numpy(img).to(dev))
+    ws = torch.empty(max(16, ops.fft2d_workspace_bytes(w, h)), dtype=torch.uint8, device=dev)
+    for c in range(3):
+        p, q = planes[c], planes[c].view(w, h)                          # cufftPlan2d(width, height)
+        spec = ops.fft2d(q, workspace=ws)
+        s2 = spec.view(h, w)
+        ops.fftshift_(s2); ops.highpass_(s2, 10.0); ops.fftshift_(s2)
+        ops.fft2d(spec, inverse=True, out=q, workspace=ws)
+        ops.normalize_zero_imag_(p)
+    assert np.array_equal(ops.complex_to_u8(*planes).cpu().numpy(), out)
+
+
 def test_fft_highpass_image_pipeline(dev, golden):
     """imageFFTImageGenerate (imageTools.cu:633-791) end to end on a power-of-two image."""
     w, h = 128, 64

@@ -493,9 +493,22 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int
     hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = mi_u8_to_complex_dev(d_img, pl, pl + n * 8, pl + 2 * n * 8, w, h, nullptr);
-        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(pl, spec, rows, cols, 3, MI_FFT_FORWARD, ws, ws_bytes, nullptr);
+        // chirp-z sizes: the tables in the cached workspace survive from the forward transform to the inverse
+        // one, and from one call to the next of the same geometry (nothing else writes there)
+        const bool chirpz = ws_bytes && !(((rows & (rows - 1)) == 0) && ((cols & (cols - 1)) == 0));
+        HostScratch::TableKey& key = *scratch.tables;
+        // any other geometry lays the buffer out differently and may have overwritten the tables
+        if (!chirpz || !(key.at == ws && key.rows == rows && key.cols == cols)) key = HostScratch::TableKey{nullptr, 0, 0};
+        auto transform = [&](const void* src, void* dst, int dir) -> int {
+            if (!chirpz) return mi_fft2d_c2c_f32_ws_dev(src, dst, rows, cols, 3, dir, ws, ws_bytes, nullptr);
+            const bool ready = key.at != nullptr;
+            const int r = launch_fft2d_any(src, dst, rows, cols, 3, dir, ws, nullptr, ready);
+            key = r == MI_OK ? HostScratch::TableKey{ws, rows, cols} : HostScratch::TableKey{nullptr, 0, 0};
+            return r;
+        };
+        if (rc == MI_OK) rc = transform(pl, spec, MI_FFT_FORWARD);
         if (rc == MI_OK) rc = edit(spec);                       // the three spectra, back to back
-        if (rc == MI_OK) rc = mi_fft2d_c2c_f32_ws_dev(spec, pl, rows, cols, 3, MI_FFT_INVERSE, ws, ws_bytes, nullptr);
+        if (rc == MI_OK) rc = transform(spec, pl, MI_FFT_INVERSE);
         // NormalizeAndZeroImaginary and ComplexRGBToUchar in one pass
         if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);

@@ -821,7 +821,8 @@ size_t fft2d_workspace_bytes(int rows, int cols)
     return (size_t)blue_layout(rows, cols).total * sizeof(c2);
 }
 
-int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws, hipStream_t s)
+int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws, hipStream_t s,
+                     bool tables_ready)
 {
     if (is_pow2(rows) && is_pow2(cols)) return launch_fft2d(in, out, rows, cols, batch, dir, s, ws);
     int rc = ensure_twiddles(s);
@@ -835,8 +836,9 @@ int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, i
         if (!t.m) return MI_OK;
         c2* chirp = tab; c2* bhat = tab + n;
         tab += n + t.m;
-        blue_tables_kernel<<<(t.m + 255) / 256, 256, 0, s>>>(chirp, bhat, n, t.m);
         t.chirp = chirp; t.bhat = bhat;
+        if (tables_ready) return MI_OK;
+        blue_tables_kernel<<<(t.m + 255) / 256, 256, 0, s>>>(chirp, bhat, n, t.m);
         return pow2_lines(bhat, t.m, bhat, t.m, 1, t.m, -1, s);
     };
     rc = make_tables(tc, cols);

@@ -95,10 +95,12 @@ struct Scratch {
     int device = -1;
     void* ptr = nullptr;
     size_t cap = 0;
+    HostScratch::TableKey tables{nullptr, 0, 0};
     void release()
     {
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr; cap = 0; device = -1;
+        tables = HostScratch::TableKey{nullptr, 0, 0};
     }
 };
 
@@ -131,6 +133,7 @@ int host_scratch(size_t bytes, HostScratch* out)
         g_scratch.device = dev;
     }
     out->ptr = g_scratch.ptr;
+    out->tables = &g_scratch.tables;
     return MI_OK;
 }
 

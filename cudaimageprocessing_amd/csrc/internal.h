@@ -54,6 +54,11 @@ int host_release();
 struct HostScratch {
     std::unique_lock<std::mutex> lock;
     void* ptr = nullptr;
+    // What the chirp-z tables at `tables_at` inside the buffer were built for (all zero: nothing): the
+    // host-tier spectral calls are the only writers of the buffer, so tables built by one call are
+    // still there for the next one of the same geometry.  Points into the cache; valid while `lock` is held.
+    struct TableKey { const void* at; int rows, cols; };
+    TableKey* tables = nullptr;
 };
 int host_scratch(size_t bytes, HostScratch* out);
 
@@ -70,8 +75,9 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
 // fft2d_workspace_bytes(rows, cols) bytes (0 when both are powers of two).
 int fft2d_size_supported(int rows, int cols);
 size_t fft2d_workspace_bytes(int rows, int cols);
+// tables_ready: the workspace still holds the chirp tables an earlier call built for these sizes
 int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws,
-                     hipStream_t s);
+                     hipStream_t s, bool tables_ready = false);
 int launch_fftshift(void* d, int w, int h, hipStream_t s);
 int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s);
 int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);

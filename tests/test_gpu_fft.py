@@ -237,6 +237,25 @@ def test_host_tier_highpass_equals_the_device_tier_steps(dev, w, h):
     assert np.array_equal(ops.complex_to_u8(*planes).cpu().numpy(), out)
 
 
+def test_host_tier_chirp_tables_survive_only_the_same_geometry(dev):
+    """The host tier keeps the chirp-z tables in its cached device buffer between calls: results must
+    not depend on what ran before (other sizes, compressImage's transposed geometry, a power of two)."""
+    def run(fn, w, h):
+        img = S.synth_image(w + h, w, h)
+        out = np.empty_like(img)
+        fn(out, img, w, h)
+        return out
+    first = {(w, h): run(ops.imageFFTImageGenerate, w, h) for (w, h) in ((67, 45), (45, 67), (90, 33))}
+    comp = run(ops.compressImage, 67, 45)
+    order = [(67, 45), (67, 45), (45, 67), (128, 64), (67, 45), (90, 33), (1024, 1024), (90, 33), (45, 67)]
+    for (w, h) in order:
+        if (w, h) in first:
+            assert np.array_equal(run(ops.imageFFTImageGenerate, w, h), first[(w, h)]), (w, h)
+        else:
+            run(ops.imageFFTImageGenerate, w, h)
+        assert np.array_equal(run(ops.compressImage, 67, 45), comp)
+
+
 def test_fft_highpass_image_pipeline(dev, golden):
     """imageFFTImageGenerate (imageTools.cu:633-791) end to end on a power-of-two image."""
     w, h = 128, 64

@@ -382,10 +382,14 @@ static int ensure_twiddles(hipStream_t s)
     if (dev < 0 || dev >= 64 || !ready[dev]) {
         // stream-ordered: the transform kernels that follow on `s` see the table; the first
         // call on a device must not race with FFT calls on other streams of that device
+        // under stream capture the fill is only recorded (it then runs with every replay of that graph):
+        // the table does not exist yet, so the next eager call still has to fill it
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
         twiddle_init_kernel<<<TW_N / 256, 256, 0, s>>>();
         e = hipGetLastError();
         if (e != hipSuccess) return hip_status(e, "twiddle table init");
-        if (dev >= 0 && dev < 64) ready[dev] = true;
+        if (dev >= 0 && dev < 64 && cap == hipStreamCaptureStatusNone) ready[dev] = true;
     }
     return MI_OK;
 }

@@ -451,3 +451,41 @@ def test_config3_full_batch(dev):
         assert torch.equal(out[f], ops.fused_chain(frames[f])), f
     del frames, out, t0, t1
     torch.cuda.empty_cache()
+
+
+def test_device_tier_runs_under_graph_capture(dev):
+    """The device tier neither allocates nor synchronises: a sequence of its calls can
+    be captured into a HIP graph and replayed, with the result of the eager calls."""
+    frames = ops.synth(31, 640, 360, batch=3)
+    outs = [torch.empty_like(frames) for _ in range(6)]
+    plane = torch.complex(torch.rand(2, 256, 128, device=dev), torch.rand(2, 256, 128, device=dev))
+    spec = torch.empty_like(plane)
+    odd = torch.complex(torch.rand(45, 67, device=dev), torch.rand(45, 67, device=dev))
+    odd_out = torch.empty_like(odd)
+    ws = torch.empty(ops.fft2d_workspace_bytes(45, 67), dtype=torch.uint8, device=dev)
+
+    def sequence():
+        ops.grayscale(frames, outs[0])
+        ops.gaussian_blur(outs[0], 5, 1.0, outs[1])
+        ops.median_blur(outs[1], 3, outs[2])
+        ops.sobel(outs[2], outs[3])
+        ops.fused_chain(frames, 1.0, outs[4])
+        ops.mean_blur(frames, 17, outs[5])
+        ops.fft2d(plane, out=spec)
+        ops.fft2d(odd, out=odd_out, workspace=ws)
+
+    sequence()                                   # eager: reference results (and every lazy one-time set-up)
+    torch.cuda.synchronize()
+    want = [o.clone() for o in outs] + [spec.clone(), odd_out.clone()]
+    for o in outs + [spec, odd_out]:
+        o.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sequence()
+    torch.cuda.synchronize()
+    assert int(outs[4].view(torch.uint8).max()) == 0          # captured, not run
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    for got, ref in zip(outs + [spec, odd_out], want):
+        assert torch.equal(got, ref)

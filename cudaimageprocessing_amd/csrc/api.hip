@@ -467,53 +467,105 @@ int mi_run_ops_chunked_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const
 int mi_host_release(void) { return host_release(); }
 
 // imageFFTImageGenerate's scaffold (imageTools.cu:633-791): u8 -> three complex planes -> forward
-// transform -> `edit` on each spectrum -> inverse -> /N, imaginary part dropped -> u8.
+// transform -> `edit` on the three spectra -> inverse -> /N, imaginary part dropped -> u8.
 // `rows` x `cols` is the geometry the transforms see (rows * cols == w * h).
+// Device core: d_in / d_out are device images (they may be the same buffer), `work` is device scratch
+// laid out as [three planes | three spectra | transform workspace]; nothing is allocated, everything
+// goes to `s`.  tables: the host tier's record of the chirp-z tables in `work` (null: rebuild them).
+static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int spectral_work_bytes(int w, int h, int rows, int cols, size_t* bytes)
+{
+    size_t ws_bytes = 0;
+    const int rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
+    if (rc) return rc;
+    *bytes = 2 * up256((size_t)w * h * 8 * 3) + ws_bytes;
+    return MI_OK;
+}
+
+extern "C++" template <class Edit>
+static int spectral_roundtrip_dev(const void* d_in, void* d_out, int w, int h, int rows, int cols, Edit edit,
+                                  void* work, HostScratch::TableKey* tables, hipStream_t s)
+{
+    const size_t n = (size_t)w * h;
+    size_t ws_bytes = 0;
+    int rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
+    if (rc) return rc;
+    const size_t planes_bytes = up256(n * 8 * 3);
+    char* pl = (char*)work;
+    char* spec = pl + planes_bytes;
+    void* ws = ws_bytes ? spec + planes_bytes : nullptr;
+    rc = mi_u8_to_complex_dev(d_in, pl, pl + n * 8, pl + 2 * n * 8, w, h, s);
+    // chirp-z sizes: the tables in a cached workspace survive from the forward transform to the inverse
+    // one, and from one call to the next of the same geometry (nothing else writes there)
+    const bool chirpz = ws_bytes && !(((rows & (rows - 1)) == 0) && ((cols & (cols - 1)) == 0));
+    HostScratch::TableKey none{nullptr, 0, 0};
+    HostScratch::TableKey& key = tables ? *tables : none;
+    // any other geometry lays the buffer out differently and may have overwritten the tables
+    if (!chirpz || !(key.at == ws && key.rows == rows && key.cols == cols)) key = HostScratch::TableKey{nullptr, 0, 0};
+    auto transform = [&](const void* src, void* dst, int dir) -> int {
+        if (!chirpz) return mi_fft2d_c2c_f32_ws_dev(src, dst, rows, cols, 3, dir, ws, ws_bytes, s);
+        const bool ready = tables && key.at != nullptr;
+        const int r = launch_fft2d_any(src, dst, rows, cols, 3, dir, ws, s, ready);
+        key = r == MI_OK ? HostScratch::TableKey{ws, rows, cols} : HostScratch::TableKey{nullptr, 0, 0};
+        return r;
+    };
+    if (rc == MI_OK) rc = transform(pl, spec, MI_FFT_FORWARD);
+    if (rc == MI_OK) rc = edit(spec);                       // the three spectra, back to back
+    if (rc == MI_OK) rc = transform(spec, pl, MI_FFT_INVERSE);
+    // NormalizeAndZeroImaginary and ComplexRGBToUchar in one pass
+    if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_out, w, h, s);
+    return rc;
+}
+
+// Host tier: one cached device buffer (the image, then the device core's scratch), blocking copies.
 extern "C++" template <class Edit>
 static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int rows, int cols, Edit edit)
 {
     int rc = check_image(in, out, w, h, 1);
     if (rc) return rc;
     const size_t n = (size_t)w * h;
-    size_t ws_bytes = 0;
-    rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
+    size_t work_bytes = 0;
+    rc = spectral_work_bytes(w, h, rows, cols, &work_bytes);
     if (rc) return rc;
-    // one cached device buffer: the image, three planes, three planes of spectrum (the transforms run out
-    // of place, where tall planes take the fast split column pass), the chirp-z workspace
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t img_bytes = up(n * 4), planes_bytes = up(n * 8 * 3);
+    const size_t img_bytes = up256(n * 4);
     HostScratch scratch;
-    rc = host_scratch(img_bytes + 2 * planes_bytes + ws_bytes, &scratch);
+    rc = host_scratch(img_bytes + work_bytes, &scratch);
     if (rc) return rc;
-    char* base = (char*)scratch.ptr;
-    void* d_img = base;
-    char* pl = base + img_bytes;
-    char* spec = pl + planes_bytes;
-    void* ws = ws_bytes ? spec + planes_bytes : nullptr;
+    char* d_img = (char*)scratch.ptr;
     hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = mi_u8_to_complex_dev(d_img, pl, pl + n * 8, pl + 2 * n * 8, w, h, nullptr);
-        // chirp-z sizes: the tables in the cached workspace survive from the forward transform to the inverse
-        // one, and from one call to the next of the same geometry (nothing else writes there)
-        const bool chirpz = ws_bytes && !(((rows & (rows - 1)) == 0) && ((cols & (cols - 1)) == 0));
-        HostScratch::TableKey& key = *scratch.tables;
-        // any other geometry lays the buffer out differently and may have overwritten the tables
-        if (!chirpz || !(key.at == ws && key.rows == rows && key.cols == cols)) key = HostScratch::TableKey{nullptr, 0, 0};
-        auto transform = [&](const void* src, void* dst, int dir) -> int {
-            if (!chirpz) return mi_fft2d_c2c_f32_ws_dev(src, dst, rows, cols, 3, dir, ws, ws_bytes, nullptr);
-            const bool ready = key.at != nullptr;
-            const int r = launch_fft2d_any(src, dst, rows, cols, 3, dir, ws, nullptr, ready);
-            key = r == MI_OK ? HostScratch::TableKey{ws, rows, cols} : HostScratch::TableKey{nullptr, 0, 0};
-            return r;
-        };
-        if (rc == MI_OK) rc = transform(pl, spec, MI_FFT_FORWARD);
-        if (rc == MI_OK) rc = edit(spec);                       // the three spectra, back to back
-        if (rc == MI_OK) rc = transform(spec, pl, MI_FFT_INVERSE);
-        // NormalizeAndZeroImaginary and ComplexRGBToUchar in one pass
-        if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_img, w, h, nullptr);
+        rc = spectral_roundtrip_dev(d_img, d_img, w, h, rows, cols, edit, d_img + img_bytes, scratch.tables, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
     }
     return rc ? rc : hip_status(e, "spectral round trip");
+}
+
+int mi_fft_highpass_workspace_bytes(int w, int h, size_t* bytes)
+{
+    if (!bytes) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive size %dx%d", w, h);
+    return spectral_work_bytes(w, h, /*rows=*/w, /*cols=*/h, bytes);
+}
+
+int mi_fft_highpass_u8x4_dev(const void* d_in, void* d_out, int w, int h, float cutoff, void* d_workspace,
+                             size_t workspace_bytes, void* stream)
+{
+    if (!d_in || !d_out || !d_workspace) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
+    size_t need = 0;
+    int rc = mi_fft_highpass_workspace_bytes(w, h, &need);
+    if (rc) return rc;
+    if (workspace_bytes < need)
+        return fail(MI_ERR_INVALID_ARG, "fft_highpass %dx%d needs a workspace of %zu bytes (got %zu)", w, h, need, workspace_bytes);
+    const size_t img = (size_t)w * h * 4;
+    if (d_in != d_out && overlap(d_in, img, d_out, img)) return fail(MI_ERR_OVERLAP, "partially overlapping images");
+    if (overlap(d_workspace, need, d_in, img) || overlap(d_workspace, need, d_out, img))
+        return fail(MI_ERR_OVERLAP, "workspace overlaps an image");
+    hipStream_t s = (hipStream_t)stream;
+    return spectral_roundtrip_dev(d_in, d_out, w, h, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
+        return launch_highpass_unshifted(spectra, w, h, 3, cutoff, s);
+    }, d_workspace, nullptr, s);
 }
 
 int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)

@@ -215,6 +215,13 @@ int mi_host_release(void);
  * square image, and what reproduces the reference's own sample output for the 675x900 one
  * (tests/golden/).  Sizes: w, h in [2, 4096], or powers of two up to 8192. */
 int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);
+/* The same on device images (d_in and d_out may be the same buffer), asynchronous on `stream`,
+ * with the caller's scratch: three planes, three spectra and the transform workspace,
+ * mi_fft_highpass_workspace_bytes(w, h) bytes (about 13 images' worth for a power-of-two size,
+ * 20 for the chirp-z sizes).  Allocates nothing: usable under stream capture like the filters. */
+int mi_fft_highpass_workspace_bytes(int w, int h, size_t *bytes);
+int mi_fft_highpass_u8x4_dev(const void *d_in, void *d_out, int w, int h, float cutoff,
+                             void *d_workspace, size_t workspace_bytes, void *stream);
 /* compressImage (declared at kernels/imageTools.h:17 and commented out at main.cpp:44, never
  * defined upstream; defined by this library on the round-trip scaffold of imageFFTImageGenerate):
  * per colour channel, forward 2-D DFT, keep the ceil(keep_fraction * w * h) coefficients of

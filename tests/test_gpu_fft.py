@@ -237,6 +237,31 @@ def test_host_tier_highpass_equals_the_device_tier_steps(dev, w, h):
     assert np.array_equal(ops.complex_to_u8(*planes).cpu().numpy(), out)
 
 
+@pytest.mark.parametrize("w,h", [(67, 45), (128, 64), (33, 40), (675, 900)])
+def test_device_tier_highpass_equals_the_host_tier_and_replays_from_a_graph(dev, w, h):
+    img = S.synth_image(3 * w + h, w, h)
+    want = np.empty_like(img)
+    ops.imageFFTImageGenerate(want, img, w, h)
+    d = torch.from_numpy(img).to(dev)
+    ws = torch.empty(ops.fft_highpass_workspace_bytes(w, h), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(d)
+    assert np.array_equal(ops.fft_highpass(d, 10.0, out, ws).cpu().numpy(), want)
+    inplace = d.clone()
+    ops.fft_highpass(inplace, 10.0, inplace, ws)
+    assert np.array_equal(inplace.cpu().numpy(), want)
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.fft_highpass(d, 10.0, out, ws)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(_lib.MiError):
+        ops.fft_highpass(d, 10.0, out, ws[:1024])
+    with pytest.raises(_lib.MiError):
+        ops.fft_highpass(d, 0.0, out, ws)
+
+
 def test_host_tier_chirp_tables_survive_only_the_same_geometry(dev):
     """The host tier keeps the chirp-z tables in its cached device buffer between calls: results must
     not depend on what ran before (other sizes, compressImage's transposed geometry, a power of two)."""

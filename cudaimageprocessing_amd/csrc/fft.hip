@@ -755,7 +755,9 @@ static int launch_blue_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_str
     });
     if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
     const i64 blocks = ((i64)nlines + LPB - 1) / LPB;
-    const int grid = (int)std::min<i64>(blocks, 256 * 8);
+    // persistent blocks, two per CU (measured: 5-8 % faster than one block per group; holding the next
+    // group's points in a second register set, as the power-of-two kernel does, was 30 % slower here)
+    const int grid = (int)std::min<i64>(blocks, 256 * (i64)std::max(1, env_int("MI_FFT_CHIRPZ_BLOCKS_PER_CU", 2)));
     blue_lines_kernel<M, LPB><<<grid, threads, lds, s>>>(src, src_stride, dst, dst_stride, nlines, n, t.chirp, t.bhat, inverse);
     return hip_status(hipGetLastError(), "chirp-z kernel launch");
 }

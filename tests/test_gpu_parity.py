@@ -453,6 +453,26 @@ def test_config3_full_batch(dev):
     torch.cuda.empty_cache()
 
 
+def test_random_shapes_for_the_tiled_kernels(dev, golden):
+    """60 seeded random cases for the LDS-tiled kernels (mean 17..31, direct Gaussian 9..15): widths around
+    multiples of the 64-pixel tile, heights around multiples of its 16 rows, images smaller than the kernel."""
+    rng = np.random.default_rng(77)
+    special_w = [3, 5, 17, 31, 63, 64, 65, 66, 127, 128, 129, 191, 192, 193, 256, 300]
+    special_h = [3, 5, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 70]
+    for case in range(60):
+        w = int(rng.choice(special_w)) if rng.random() < 0.7 else int(rng.integers(3, 400))
+        h = int(rng.choice(special_h)) if rng.random() < 0.7 else int(rng.integers(3, 120))
+        img = make(str(rng.choice(PATTERNS)), w, h, int(rng.integers(1, 1 << 30)))
+        d = to_dev(img, dev)
+        if rng.random() < 0.5:
+            k = int(rng.choice([17, 19, 21, 23, 25, 27, 29, 31]))
+            assert np.array_equal(host(ops.mean_blur(d, k)), golden.meanblur(img, k)), (case, w, h, "mean", k)
+        else:
+            k = int(rng.choice([9, 11, 13, 15]))
+            sigma = float(rng.uniform(0.8, 5.0))
+            assert np.array_equal(host(ops.gaussian_blur(d, k, sigma, direct=True)), golden.gaussian(img, k, sigma)), (case, w, h, "direct", k, sigma)
+
+
 def test_device_tier_runs_under_graph_capture(dev):
     """The device tier neither allocates nor synchronises: a sequence of its calls can
     be captured into a HIP graph and replayed, with the result of the eager calls."""

@@ -593,16 +593,14 @@ int mi_compress_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float keep_f
         return fail(MI_ERR_INVALID_ARG, "keep_fraction must be in (0, 1] (got %g)", (double)keep_fraction);
     const size_t n = (size_t)w * h;
     return spectral_roundtrip(in, out, w, h, /*rows=*/h, /*cols=*/w, [&](char* spectra) {
-        int rc = MI_OK;
-        for (int c = 0; c < 3 && rc == MI_OK; c++) rc = spectrum_keep_top(spectra + c * n * 8, n, keep_count(n, keep_fraction), nullptr);
-        return rc;
+        return spectrum_keep_top(spectra, n, keep_count(n, keep_fraction), 3, nullptr);
     });
 }
 
 int mi_spectrum_keep_top_dev(void* d_data, size_t n, size_t keep, void* stream)
 {
     if (!d_data || n == 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
-    return spectrum_keep_top(d_data, n, keep, (hipStream_t)stream);
+    return spectrum_keep_top(d_data, n, keep, 1, (hipStream_t)stream);
 }
 
 int mi_gaussian_kernel(int kernel_size, float sigma, float* out)

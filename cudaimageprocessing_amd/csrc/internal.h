@@ -84,7 +84,7 @@ int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);
 int launch_complex_to_u8(const void* r, const void* g, const void* b, void* out, int w, int h,
                          hipStream_t s);
 // Zero all but the `keep` coefficients of largest magnitude (blocking; ties at the threshold stay).
-int spectrum_keep_top(void* data, size_t n, size_t keep, hipStream_t s);
+int spectrum_keep_top(void* data, size_t n, size_t keep, int planes, hipStream_t s);
 int launch_minmax(const void* img, size_t n, void* minmax, hipStream_t s);
 int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* minmax,
                            hipStream_t s);

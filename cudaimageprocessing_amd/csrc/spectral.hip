@@ -286,72 +286,92 @@ int launch_normalize_to_u8(const void* img, void* out, size_t n, const void* min
 MI_DEV u32 mag2_bits(f32x2v v) { return __float_as_uint(v.x * v.x + v.y * v.y); }
 
 constexpr int SEL_BINS = 2048;
+constexpr int SEL_MAX_PLANES = 4;
+struct SelPrefix { u32 v[SEL_MAX_PLANES]; };
 
-// hist[digit] += 1 for every value whose bits above `shift + width` equal `prefix`
-__global__ __launch_bounds__(256) void mag_hist_kernel(const f32x2v* __restrict__ d, i64 n, u32 prefix,
+// blockIdx.y = plane (planes are back to back, n values each).
+// hist[plane][digit] += 1 for every value of the plane whose bits above `shift + width` equal the plane's prefix
+__global__ __launch_bounds__(256) void mag_hist_kernel(const f32x2v* __restrict__ d, i64 n, SelPrefix prefix,
                                                        int prefix_shift, int shift, u32 digit_mask,
                                                        u32* __restrict__ hist)
 {
     __shared__ u32 local[SEL_BINS];
     for (int b = threadIdx.x; b < SEL_BINS; b += 256) local[b] = 0;
     __syncthreads();
+    const int plane = blockIdx.y;
+    const u32 want = prefix.v[plane];
+    d += (i64)plane * n;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const u32 b = mag2_bits(d[i]);
-        if (prefix_shift >= 32 || (b >> prefix_shift) == prefix) atomicAdd(&local[(b >> shift) & digit_mask], 1u);
+        if (prefix_shift >= 32 || (b >> prefix_shift) == want) atomicAdd(&local[(b >> shift) & digit_mask], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < SEL_BINS; b += 256)
-        if (local[b]) atomicAdd(&hist[b], local[b]);
+        if (local[b]) atomicAdd(&hist[plane * SEL_BINS + b], local[b]);
 }
 
-__global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i64 n, u32 threshold)
+__global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i64 n, SelPrefix threshold)
 {
+    const u32 thr = threshold.v[blockIdx.y];
+    d += (i64)blockIdx.y * n;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (mag2_bits(d[i]) < threshold) d[i] = f32x2v{0.f, 0.f};
+        if (mag2_bits(d[i]) < thr) d[i] = f32x2v{0.f, 0.f};
 }
 
-// Blocking: reads the three histograms back on the host.
-int spectrum_keep_top(void* data, size_t n, size_t keep, hipStream_t s)
+// `planes` spectra of n values each, back to back, each keeping its own `keep` largest.
+// Blocking: reads three histograms per plane back on the host (one read-back per level for all planes).
+int spectrum_keep_top(void* data, size_t n, size_t keep, int planes, hipStream_t s)
 {
-    if (keep >= n) return MI_OK;
-    const int grid = std::min(flat_grid((i64)n, 4), 1024);
-    if (keep == 0) {
-        mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, 0xffffffffu);   // nothing survives
-        return hip_status(hipGetLastError(), "spectrum_keep_top");
-    }
-    u32* d_hist = nullptr;
-    hipError_t e = hipMalloc((void**)&d_hist, SEL_BINS * sizeof(u32));
-    if (e != hipSuccess) return hip_status(e, "spectrum histogram");
-    std::vector<u32> hist(SEL_BINS);
-    // digits, most significant first: (shift, width)
-    const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
-    u32 prefix = 0;
-    size_t want = keep;                 // rank of the threshold among the values sharing `prefix`, from the top
-    for (int level = 0; level < 3 && e == hipSuccess; level++) {
-        const int shift = shifts[level], prefix_shift = level == 0 ? 32 : shifts[level - 1];
-        e = hipMemsetAsync(d_hist, 0, SEL_BINS * sizeof(u32), s);
-        if (e != hipSuccess) break;
-        mag_hist_kernel<<<grid, 256, 0, s>>>((const f32x2v*)data, (i64)n, prefix, prefix_shift, shift,
-                                             (1u << widths[level]) - 1u, d_hist);
-        e = hipMemcpyAsync(hist.data(), d_hist, SEL_BINS * sizeof(u32), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) break;
-        size_t above = 0;
-        u32 digit = 0;
-        for (int b = (1 << widths[level]) - 1; b >= 0; b--) {
-            if (above + hist[b] >= want) { digit = (u32)b; want -= above; break; }
-            above += hist[b];
+    if (keep >= n || planes <= 0) return MI_OK;
+    int rc = MI_OK;
+    for (int p0 = 0; p0 < planes && rc == MI_OK; p0 += SEL_MAX_PLANES) {
+        const int np = std::min(SEL_MAX_PLANES, planes - p0);
+        f32x2v* base = (f32x2v*)data + (size_t)p0 * n;
+        const dim3 grid(std::min(flat_grid((i64)n, 4), 1024), np);
+        SelPrefix prefix{};
+        if (keep == 0) {
+            for (int p = 0; p < np; p++) prefix.v[p] = 0xffffffffu;        // nothing survives
+            mag_mask_kernel<<<grid, 256, 0, s>>>(base, (i64)n, prefix);
+            rc = hip_status(hipGetLastError(), "spectrum_keep_top");
+            continue;
         }
-        prefix = (prefix << widths[level]) | digit;
+        u32* d_hist = nullptr;
+        hipError_t e = hipMalloc((void**)&d_hist, (size_t)np * SEL_BINS * sizeof(u32));
+        if (e != hipSuccess) return hip_status(e, "spectrum histogram");
+        std::vector<u32> hist((size_t)np * SEL_BINS);
+        // digits, most significant first: (shift, width)
+        const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
+        size_t want[SEL_MAX_PLANES];     // rank of the threshold among the values sharing the prefix, from the top
+        for (int p = 0; p < np; p++) want[p] = keep;
+        for (int level = 0; level < 3 && e == hipSuccess; level++) {
+            const int shift = shifts[level], prefix_shift = level == 0 ? 32 : shifts[level - 1];
+            e = hipMemsetAsync(d_hist, 0, hist.size() * sizeof(u32), s);
+            if (e != hipSuccess) break;
+            mag_hist_kernel<<<grid, 256, 0, s>>>(base, (i64)n, prefix, prefix_shift, shift, (1u << widths[level]) - 1u, d_hist);
+            e = hipMemcpyAsync(hist.data(), d_hist, hist.size() * sizeof(u32), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) break;
+            for (int p = 0; p < np; p++) {
+                const u32* h = hist.data() + (size_t)p * SEL_BINS;
+                size_t above = 0;
+                u32 digit = 0;
+                for (int b = (1 << widths[level]) - 1; b >= 0; b--) {
+                    if (above + h[b] >= want[p]) { digit = (u32)b; want[p] -= above; break; }
+                    above += h[b];
+                }
+                prefix.v[p] = (prefix.v[p] << widths[level]) | digit;
+            }
+        }
+        if (e == hipSuccess) {
+            mag_mask_kernel<<<grid, 256, 0, s>>>(base, (i64)n, prefix);   // after three levels the prefix is the threshold
+            e = hipGetLastError();
+        }
+        (void)hipFree(d_hist);
+        rc = hip_status(e, "spectrum_keep_top");
     }
-    if (e == hipSuccess) {
-        mag_mask_kernel<<<grid, 256, 0, s>>>((f32x2v*)data, (i64)n, prefix);   // after three levels the prefix is the threshold
-        e = hipGetLastError();
-    }
-    (void)hipFree(d_hist);
-    return hip_status(e, "spectrum_keep_top");
+    return rc;
 }
 
 }  // namespace mi

@@ -152,3 +152,40 @@ def test_config1_sample_image_gray_gauss_png(dev, golden, tmp_path):
     ops.imageWriteWrapper(path, out, w, h)
     assert np.array_equal(_png_pixels(path), out)
     assert np.array_equal(np.asarray(Image.open(path)), out)
+
+
+def test_host_tier_calls_from_several_threads(dev):
+    """The host tier keeps cached staging and scratch buffers behind mutexes: calls from concurrent
+    threads (ctypes releases the GIL) serialise and give the single-threaded results."""
+    import threading
+    w, h = 333, 217
+    imgs = [S.synth_image(900 + i, w, h) for i in range(4)]
+    spec = ops.parse_ops("gray,gauss:5:1.0,median:3,sobel")
+
+    def work(img):
+        a = np.empty_like(img); ops.run_ops(a, img, w, h, spec)
+        b = np.empty_like(img); ops.imageFFTImageGenerate(b, img, w, h)
+        c = np.empty_like(img); ops.compressImage(c, img, w, h, 0.2)
+        d = np.empty_like(img); ops.imageMeanBlurWrapper(d, img, w, h)
+        return a, b, c, d
+
+    want = [work(img) for img in imgs]
+    got = [[None] * 6 for _ in imgs]
+    errors = []
+
+    def runner(i, rep):
+        try:
+            got[i][rep] = work(imgs[i])
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=runner, args=(i, rep)) for rep in range(6) for i in range(len(imgs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(imgs)):
+        for rep in range(6):
+            for x, y in zip(got[i][rep], want[i]):
+                assert np.array_equal(x, y)

@@ -10,6 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats.log 2>&1 || { echo "stats pass failed"; tail -5 $out/${tag}_stats.log; exit 1; }
+grep -h '^{"metric' $out/${tag}_stats.log > $out/${tag}_bench_line_profiled.json   # bench.py's own line from the profiled process
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/${tag}_pmc_$c.log; exit 1; }
 done

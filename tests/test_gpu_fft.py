@@ -53,7 +53,8 @@ def test_fft2d_forward_and_inverse_match_oracle(dev, golden, rows, cols):
 
 
 ODD_SHAPES = [(3, 5), (2, 7), (6, 10), (15, 17), (100, 64), (64, 100), (31, 1000), (243, 125),
-              (900, 675), (2000, 2592 // 2), (4096, 3), (5, 8192), (4095, 6)]
+              (900, 675), (2000, 2592 // 2), (4096, 3), (5, 8192), (4095, 6),
+              (40, 300), (500, 48)]     # padded lengths 128 and 1024: with the rest, every m from 8 to 8192
 
 
 @pytest.mark.parametrize("rows,cols", ODD_SHAPES)

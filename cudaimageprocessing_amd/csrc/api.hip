@@ -474,28 +474,29 @@ int mi_host_release(void) { return host_release(); }
 // goes to `s`.  tables: the host tier's record of the chirp-z tables in `work` (null: rebuild them).
 static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-static int spectral_work_bytes(int w, int h, int rows, int cols, size_t* bytes)
+static int spectral_work_bytes(int w, int h, int rows, int cols, int batch, size_t* bytes)
 {
     size_t ws_bytes = 0;
     const int rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
     if (rc) return rc;
-    *bytes = 2 * up256((size_t)w * h * 8 * 3) + ws_bytes;
+    *bytes = 2 * up256((size_t)w * h * 8 * 3 * batch) + ws_bytes;
     return MI_OK;
 }
 
 extern "C++" template <class Edit>
-static int spectral_roundtrip_dev(const void* d_in, void* d_out, int w, int h, int rows, int cols, Edit edit,
+static int spectral_roundtrip_dev(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, Edit edit,
                                   void* work, HostScratch::TableKey* tables, hipStream_t s)
 {
+    const int planes = 3 * batch;      // image k's colour planes are planes 3k, 3k+1, 3k+2
     const size_t n = (size_t)w * h;
     size_t ws_bytes = 0;
     int rc = mi_fft2d_workspace_bytes(rows, cols, &ws_bytes);
     if (rc) return rc;
-    const size_t planes_bytes = up256(n * 8 * 3);
+    const size_t planes_bytes = up256(n * 8 * planes);
     char* pl = (char*)work;
     char* spec = pl + planes_bytes;
     void* ws = ws_bytes ? spec + planes_bytes : nullptr;
-    rc = mi_u8_to_complex_dev(d_in, pl, pl + n * 8, pl + 2 * n * 8, w, h, s);
+    rc = launch_u8_to_complex(d_in, pl, pl + n * 8, pl + 2 * n * 8, w, h, s, batch);
     // chirp-z sizes: the tables in a cached workspace survive from the forward transform to the inverse
     // one, and from one call to the next of the same geometry (nothing else writes there)
     const bool chirpz = ws_bytes && !(((rows & (rows - 1)) == 0) && ((cols & (cols - 1)) == 0));
@@ -504,9 +505,9 @@ static int spectral_roundtrip_dev(const void* d_in, void* d_out, int w, int h, i
     // any other geometry lays the buffer out differently and may have overwritten the tables
     if (!chirpz || !(key.at == ws && key.rows == rows && key.cols == cols)) key = HostScratch::TableKey{nullptr, 0, 0};
     auto transform = [&](const void* src, void* dst, int dir) -> int {
-        if (!chirpz) return mi_fft2d_c2c_f32_ws_dev(src, dst, rows, cols, 3, dir, ws, ws_bytes, s);
+        if (!chirpz) return mi_fft2d_c2c_f32_ws_dev(src, dst, rows, cols, planes, dir, ws, ws_bytes, s);
         const bool ready = tables && key.at != nullptr;
-        const int r = launch_fft2d_any(src, dst, rows, cols, 3, dir, ws, s, ready);
+        const int r = launch_fft2d_any(src, dst, rows, cols, planes, dir, ws, s, ready);
         key = r == MI_OK ? HostScratch::TableKey{ws, rows, cols} : HostScratch::TableKey{nullptr, 0, 0};
         return r;
     };
@@ -514,7 +515,7 @@ static int spectral_roundtrip_dev(const void* d_in, void* d_out, int w, int h, i
     if (rc == MI_OK) rc = edit(spec);                       // the three spectra, back to back
     if (rc == MI_OK) rc = transform(spec, pl, MI_FFT_INVERSE);
     // NormalizeAndZeroImaginary and ComplexRGBToUchar in one pass
-    if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_out, w, h, s);
+    if (rc == MI_OK) rc = launch_complex_to_u8_normalized(pl, pl + n * 8, pl + 2 * n * 8, d_out, w, h, batch, s);
     return rc;
 }
 
@@ -526,7 +527,7 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int
     if (rc) return rc;
     const size_t n = (size_t)w * h;
     size_t work_bytes = 0;
-    rc = spectral_work_bytes(w, h, rows, cols, &work_bytes);
+    rc = spectral_work_bytes(w, h, rows, cols, 1, &work_bytes);
     if (rc) return rc;
     const size_t img_bytes = up256(n * 4);
     HostScratch scratch;
@@ -535,37 +536,50 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int
     char* d_img = (char*)scratch.ptr;
     hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = spectral_roundtrip_dev(d_img, d_img, w, h, rows, cols, edit, d_img + img_bytes, scratch.tables, nullptr);
+        rc = spectral_roundtrip_dev(d_img, d_img, w, h, 1, rows, cols, edit, d_img + img_bytes, scratch.tables, nullptr);
         if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
     }
     return rc ? rc : hip_status(e, "spectral round trip");
 }
 
-int mi_fft_highpass_workspace_bytes(int w, int h, size_t* bytes)
+int mi_fft_highpass_batch_workspace_bytes(int w, int h, int batch, size_t* bytes)
 {
     if (!bytes) return fail(MI_ERR_INVALID_ARG, "null pointer");
-    if (w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive size %dx%d", w, h);
-    return spectral_work_bytes(w, h, /*rows=*/w, /*cols=*/h, bytes);
+    if (w <= 0 || h <= 0 || batch <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive size %dx%d or batch %d", w, h, batch);
+    if ((uint64_t)batch * 3 > 0x3fffffffu) return fail(MI_ERR_UNSUPPORTED, "batch too large");
+    return spectral_work_bytes(w, h, /*rows=*/w, /*cols=*/h, batch, bytes);
+}
+
+int mi_fft_highpass_workspace_bytes(int w, int h, size_t* bytes)
+{
+    return mi_fft_highpass_batch_workspace_bytes(w, h, 1, bytes);
+}
+
+int mi_fft_highpass_batch_u8x4_dev(const void* d_in, void* d_out, int w, int h, int batch, float cutoff,
+                                   void* d_workspace, size_t workspace_bytes, void* stream)
+{
+    if (!d_in || !d_out || !d_workspace) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
+    size_t need = 0;
+    int rc = mi_fft_highpass_batch_workspace_bytes(w, h, batch, &need);
+    if (rc) return rc;
+    if (batch > 65535) return fail(MI_ERR_UNSUPPORTED, "at most 65535 images per call (got %d)", batch);
+    if (workspace_bytes < need)
+        return fail(MI_ERR_INVALID_ARG, "fft_highpass %dx%d x%d needs a workspace of %zu bytes (got %zu)", w, h, batch, need, workspace_bytes);
+    const size_t img = (size_t)w * h * 4 * batch;
+    if (d_in != d_out && overlap(d_in, img, d_out, img)) return fail(MI_ERR_OVERLAP, "partially overlapping images");
+    if (overlap(d_workspace, need, d_in, img) || overlap(d_workspace, need, d_out, img))
+        return fail(MI_ERR_OVERLAP, "workspace overlaps an image");
+    hipStream_t s = (hipStream_t)stream;
+    return spectral_roundtrip_dev(d_in, d_out, w, h, batch, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
+        return launch_highpass_unshifted(spectra, w, h, 3 * batch, cutoff, s);
+    }, d_workspace, nullptr, s);
 }
 
 int mi_fft_highpass_u8x4_dev(const void* d_in, void* d_out, int w, int h, float cutoff, void* d_workspace,
                              size_t workspace_bytes, void* stream)
 {
-    if (!d_in || !d_out || !d_workspace) return fail(MI_ERR_INVALID_ARG, "null pointer");
-    if (!(cutoff > 0.0f)) return fail(MI_ERR_INVALID_ARG, "cutoff must be positive");
-    size_t need = 0;
-    int rc = mi_fft_highpass_workspace_bytes(w, h, &need);
-    if (rc) return rc;
-    if (workspace_bytes < need)
-        return fail(MI_ERR_INVALID_ARG, "fft_highpass %dx%d needs a workspace of %zu bytes (got %zu)", w, h, need, workspace_bytes);
-    const size_t img = (size_t)w * h * 4;
-    if (d_in != d_out && overlap(d_in, img, d_out, img)) return fail(MI_ERR_OVERLAP, "partially overlapping images");
-    if (overlap(d_workspace, need, d_in, img) || overlap(d_workspace, need, d_out, img))
-        return fail(MI_ERR_OVERLAP, "workspace overlaps an image");
-    hipStream_t s = (hipStream_t)stream;
-    return spectral_roundtrip_dev(d_in, d_out, w, h, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
-        return launch_highpass_unshifted(spectra, w, h, 3, cutoff, s);
-    }, d_workspace, nullptr, s);
+    return mi_fft_highpass_batch_u8x4_dev(d_in, d_out, w, h, 1, cutoff, d_workspace, workspace_bytes, stream);
 }
 
 int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cutoff)

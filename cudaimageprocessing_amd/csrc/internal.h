@@ -65,8 +65,8 @@ int host_scratch(size_t bytes, HostScratch* out);
 // FFT path
 // host-tier fusions of the pointwise spectral steps (bit-identical to the separate kernels)
 int launch_highpass_unshifted(void* d, int w, int h, int planes, float cutoff, hipStream_t s);
-int launch_complex_to_u8_normalized(const void* r, const void* g, const void* b, void* out, int w, int h, hipStream_t s);
-int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s);
+int launch_complex_to_u8_normalized(const void* r, const void* g, const void* b, void* out, int w, int h, int batch, hipStream_t s);
+int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s, int batch = 1);
 // tmp: optional scratch of one plane (rows*cols*8 bytes) that lets a tall plane (rows >= 1024) be
 // transformed in place at full speed; may be null.
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s,

@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void u8_to_complex_kernel(const u32* __restric
                                                             f32x2v* __restrict__ g,
                                                             f32x2v* __restrict__ b, i64 n)
 {
+    // blockIdx.y = image of a batch: images back to back, and so are the plane triples (r, g, b of image k
+    // at 3 k n, (3 k + 1) n, (3 k + 2) n from `r` when g = r + n, b = r + 2 n)
+    in += (i64)blockIdx.y * n;
+    r += (i64)blockIdx.y * 3 * n; g += (i64)blockIdx.y * 3 * n; b += (i64)blockIdx.y * 3 * n;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const u32 p = in[i];
@@ -115,6 +119,8 @@ __global__ __launch_bounds__(256) void complex_to_u8_normalized_kernel(const f32
                                                                        const f32x2v* __restrict__ b,
                                                                        u32* __restrict__ out, i64 n, float div)
 {
+    out += (i64)blockIdx.y * n;        // blockIdx.y = image of a batch (see u8_to_complex_kernel)
+    r += (i64)blockIdx.y * 3 * n; g += (i64)blockIdx.y * 3 * n; b += (i64)blockIdx.y * 3 * n;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         out[i] = sat_u8(r[i].x / div) | (sat_u8(g[i].x / div) << 8) | (sat_u8(b[i].x / div) << 16) | 0xFF000000u;
@@ -209,10 +215,10 @@ __global__ __launch_bounds__(256) void normalize_to_u8_kernel(const float* __res
     }
 }
 
-int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s)
+int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h, hipStream_t s, int batch)
 {
     const i64 n = (i64)w * h;
-    u8_to_complex_kernel<<<flat_grid(n), 256, 0, s>>>((const u32*)in, (f32x2v*)r, (f32x2v*)g, (f32x2v*)b, n);
+    u8_to_complex_kernel<<<dim3(flat_grid(n), batch), 256, 0, s>>>((const u32*)in, (f32x2v*)r, (f32x2v*)g, (f32x2v*)b, n);
     return hip_status(hipGetLastError(), "u8_to_complex launch");
 }
 
@@ -244,10 +250,10 @@ int launch_highpass_unshifted(void* d, int w, int h, int planes, float cutoff, h
     return hip_status(hipGetLastError(), "highpass launch");
 }
 
-int launch_complex_to_u8_normalized(const void* r, const void* g, const void* b, void* out, int w, int h, hipStream_t s)
+int launch_complex_to_u8_normalized(const void* r, const void* g, const void* b, void* out, int w, int h, int batch, hipStream_t s)
 {
     const i64 n = (i64)w * h;
-    complex_to_u8_normalized_kernel<<<flat_grid(n), 256, 0, s>>>((const f32x2v*)r, (const f32x2v*)g, (const f32x2v*)b,
+    complex_to_u8_normalized_kernel<<<dim3(flat_grid(n), batch), 256, 0, s>>>((const f32x2v*)r, (const f32x2v*)g, (const f32x2v*)b,
                                                                  (u32*)out, n, (float)(w * h));
     return hip_status(hipGetLastError(), "complex_to_u8 launch");
 }

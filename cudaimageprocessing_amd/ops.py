@@ -356,23 +356,25 @@ def run_ops(returnImage, imageLoaded, width, height, ops_list, chunk_rows=None):
         check(lib().mi_run_ops_chunked_u8x4(src, dst, width, height, arr, len(ops_list), int(chunk_rows)))
 
 
-def fft_highpass_workspace_bytes(width, height):
+def fft_highpass_workspace_bytes(width, height, batch=1):
     n = C.c_size_t(0)
-    check(lib().mi_fft_highpass_workspace_bytes(int(width), int(height), C.byref(n)))
+    check(lib().mi_fft_highpass_batch_workspace_bytes(int(width), int(height), int(batch), C.byref(n)))
     return int(n.value)
 
 
 def fft_highpass(img, cutoff=10.0, out=None, workspace=None):
-    """imageFFTImageGenerate on a device image (h, w, 4) uint8: the device tier of mi_fft_highpass_u8x4."""
+    """imageFFTImageGenerate on device images, (h, w, 4) or a batch (b, h, w, 4) of uint8: the device tier
+    of mi_fft_highpass_u8x4."""
     torch = _torch()
-    assert img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 3 and img.shape[2] == 4
-    h, w = int(img.shape[0]), int(img.shape[1])
+    assert img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous() and img.dim() in (3, 4) and img.shape[-1] == 4
+    h, w = int(img.shape[-3]), int(img.shape[-2])
+    batch = int(img.shape[0]) if img.dim() == 4 else 1
     if out is None:
         out = torch.empty_like(img)
     if workspace is None:
-        workspace = torch.empty(fft_highpass_workspace_bytes(w, h), dtype=torch.uint8, device=img.device)
-    check(lib().mi_fft_highpass_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, float(cutoff), workspace.data_ptr(),
-                                         workspace.numel(), _stream()))
+        workspace = torch.empty(fft_highpass_workspace_bytes(w, h, batch), dtype=torch.uint8, device=img.device)
+    check(lib().mi_fft_highpass_batch_u8x4_dev(img.data_ptr(), out.data_ptr(), w, h, batch, float(cutoff),
+                                               workspace.data_ptr(), workspace.numel(), _stream()))
     return out
 
 

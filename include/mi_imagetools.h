@@ -222,6 +222,12 @@ int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cu
 int mi_fft_highpass_workspace_bytes(int w, int h, size_t *bytes);
 int mi_fft_highpass_u8x4_dev(const void *d_in, void *d_out, int w, int h, float cutoff,
                              void *d_workspace, size_t workspace_bytes, void *stream);
+/* A batch of `batch` images of one size, back to back (the reference handles one image per call:
+ * no counterpart upstream; each image comes out as mi_fft_highpass_u8x4_dev gives it).  All 3*batch
+ * colour planes go through every step together, which is what makes small images cheap. */
+int mi_fft_highpass_batch_workspace_bytes(int w, int h, int batch, size_t *bytes);
+int mi_fft_highpass_batch_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, float cutoff,
+                                   void *d_workspace, size_t workspace_bytes, void *stream);
 /* compressImage (declared at kernels/imageTools.h:17 and commented out at main.cpp:44, never
  * defined upstream; defined by this library on the round-trip scaffold of imageFFTImageGenerate):
  * per colour channel, forward 2-D DFT, keep the ceil(keep_fraction * w * h) coefficients of

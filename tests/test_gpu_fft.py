@@ -263,6 +263,19 @@ def test_device_tier_highpass_equals_the_host_tier_and_replays_from_a_graph(dev,
         ops.fft_highpass(d, 0.0, out, ws)
 
 
+@pytest.mark.parametrize("w,h,batch", [(67, 45, 5), (128, 64, 3), (90, 33, 8), (675, 900, 2)])
+def test_device_tier_highpass_batch_equals_single_images(dev, w, h, batch):
+    frames = torch.from_numpy(np.stack([S.synth_image(50 + 7 * k + w, w, h) for k in range(batch)])).to(dev)
+    got = ops.fft_highpass(frames)
+    for k in range(batch):
+        assert torch.equal(got[k], ops.fft_highpass(frames[k].contiguous())), k
+    inplace = frames.clone()
+    ops.fft_highpass(inplace, out=inplace)
+    assert torch.equal(inplace, got)
+    with pytest.raises(_lib.MiError):
+        ops.fft_highpass(frames, workspace=torch.empty(ops.fft_highpass_workspace_bytes(w, h, 1), dtype=torch.uint8, device=dev))
+
+
 def test_host_tier_chirp_tables_survive_only_the_same_geometry(dev):
     """The host tier keeps the chirp-z tables in its cached device buffer between calls: results must
     not depend on what ran before (other sizes, compressImage's transposed geometry, a power of two)."""

@@ -448,24 +448,32 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 #pragma unroll
     for (int i = 0; i < K - 1; i++)
         hrow(load_row(mch.row(i - R)), win[i]);
+    // DEEP (9x9): two rows in flight, in three register sets that rotate with the step -- the loop is
+    // unrolled by K = 9, a multiple of 3, so the set index is static and no row is ever copied.  Measured:
+    // 308 -> 264 us; no gain for 3x3..7x7 (memory- or VALU-bound, and 5x5 / 7x7 would need 3K steps unrolled).
+    constexpr bool DEEP = R == 4;              // (15x15, also a multiple of 3, has no registers for a third row: 2.5x slower)
+    constexpr int UNR = K;
+    RowIn pf[3];
     RowIn nxt = load_row(mch.row(R));
+    if constexpr (DEEP) { pf[0] = nxt; pf[1] = load_row(mch.row(R + 1)); }
 
-    for (int base = 0; base < mch.n; base += K) {
+    for (int base = 0; base < mch.n; base += UNR) {
 #pragma unroll
-        for (int s = 0; s < K; s++) {
+        for (int s = 0; s < UNR; s++) {
             const int i = base + s;
             // the next row is requested on every step, valid or not (a load beyond the band is harmless):
             // assigned unconditionally, `nxt` needs no merge at the end of the guarded block below, and
             // so no register copy that would make the wave wait for the load it has just issued
             // (only where registers allow both rows to be live: the wide kernels keep the load in the block)
-            constexpr bool EAGER = R <= 4;
-            const RowIn cur = nxt;
+            constexpr bool EAGER = R <= 4 && !DEEP;
+            if constexpr (DEEP) pf[(s + 2) % 3] = load_row(mch.row(i + R + 2));
+            const RowIn cur = DEEP ? pf[s % 3] : nxt;
             if constexpr (EAGER) nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
             hrow(cur, win[(K - 1 + s) % K]);
-            if constexpr (!EAGER) nxt = load_row(mch.row(i + R + 1));
+            if constexpr (!EAGER && !DEEP) nxt = load_row(mch.row(i + R + 1));
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -565,13 +573,19 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
 #pragma unroll
         for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[i][e]);
     }
+    // (see gauss_sep_kernel: the next row is requested unconditionally; 9x9 keeps two rows in flight)
+    constexpr bool DEEP = R >= 3 && R != 6;   // 13x13 would unroll 39 steps: measured 2.6x slower (instruction cache)
+    constexpr int UNR = DEEP && K % 3 != 0 ? 3 * K : K;   // a multiple of K (window slots) and of 3 (row sets)
+    RowIn pf[3];
     RowIn nxt = load_row(mch.row(R));
-    for (int base = 0; base < mch.n; base += K) {
+    if constexpr (DEEP) { pf[0] = nxt; pf[1] = load_row(mch.row(R + 1)); }
+    for (int base = 0; base < mch.n; base += UNR) {
 #pragma unroll
-        for (int s = 0; s < K; s++) {
+        for (int s = 0; s < UNR; s++) {
             const int i = base + s;
-            const RowIn cur = nxt;   // see gauss_sep_kernel: the next row is requested unconditionally
-            nxt = load_row(mch.row(i + R + 1));
+            if constexpr (DEEP) pf[(s + 2) % 3] = load_row(mch.row(i + R + 2));
+            const RowIn cur = DEEP ? pf[s % 3] : nxt;
+            if constexpr (!DEEP) nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // rows y-R+t live in slot (s+t)%K; the newest one, y+R, replaces the row dropped last step

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mi_fft_highpass_u8x4": [_vp, _vp, _i, _i, _f],
     "mi_fft_highpass_workspace_bytes": [_i, _i, _vp],
     "mi_fft_highpass_u8x4_dev": [_vp, _vp, _i, _i, _f, _vp, _sz, _vp],
+    "mi_fft_highpass_u8x4_static_dev": [_vp, _vp, _i, _i, _f, _vp],
     "mi_fft_highpass_batch_workspace_bytes": [_i, _i, _i, _vp],
     "mi_fft_highpass_batch_u8x4_dev": [_vp, _vp, _i, _i, _i, _f, _vp, _sz, _vp],
     "mi_compress_u8x4": [_vp, _vp, _i, _i, _f],

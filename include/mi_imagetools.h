@@ -222,6 +222,19 @@ int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cu
 int mi_fft_highpass_workspace_bytes(int w, int h, size_t *bytes);
 int mi_fft_highpass_u8x4_dev(const void *d_in, void *d_out, int w, int h, float cutoff,
                              void *d_workspace, size_t workspace_bytes, void *stream);
+/* No counterpart in the reference: mi_fft_highpass_u8x4_dev for callers that cannot allocate (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc) and so have no
+ * workspace to bring.  The scratch is a static device array inside the library, MI_STATIC_SCRATCH_BYTES
+ * per GPU, held until the process ends; the call allocates nothing (no hipMalloc / hipFree, no
+ * allocating library routine) and its output is byte-identical to mi_fft_highpass_u8x4_dev's.
+ * Sizes whose workspace (mi_fft_highpass_workspace_bytes) exceeds the static buffer return
+ * MI_ERR_UNSUPPORTED: the limit covers the reference's 675x900 demo image and powers of two up to
+ * 1024x1024.  All calls on one GPU share that GPU's buffer: calls that overlap in time on one GPU
+ * (two streams, two threads) race; stream-ordered calls are safe.  The first call on a device looks
+ * the buffer's address up (and fills the FFT twiddle table): make it outside stream capture. */
+#define MI_STATIC_SCRATCH_BYTES (64u << 20)
+int mi_fft_highpass_u8x4_static_dev(const void *d_in, void *d_out, int w, int h, float cutoff,
+                                    void *stream);
 /* A batch of `batch` images of one size, back to back (the reference handles one image per call:
  * no counterpart upstream; each image comes out as mi_fft_highpass_u8x4_dev gives it).  All 3*batch
  * colour planes go through every step together, which is what makes small images cheap. */

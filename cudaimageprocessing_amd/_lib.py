@@ -62,6 +62,7 @@ SIGNATURES = {
     "mi_spectrum_keep_top_dev": [_vp, _sz, _sz, _vp],
     "mi_selftest": [],
     "mi_gaussian_kernel": [_i, _f, _vp],
+    "mi_debug_set_tuning": [C.c_char_p, _i],
     "mi_version": [],
     "mi_device_count": [],
 }

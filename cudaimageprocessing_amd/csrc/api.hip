@@ -32,6 +32,44 @@ int hip_status(hipError_t e, const char* what)
     return (int)e;
 }
 
+// ---------------------------------------------------------------- tuning knobs
+namespace {
+struct Knob { const char* name; int Tuning::*field; };
+const Knob KNOBS[] = {
+    {"MI_ROWS_PER_BAND", &Tuning::rows_per_band}, {"MI_CHAIN_ROWS_PER_BAND", &Tuning::chain_rows_per_band},
+    {"MI_CHAIN_MARGIN", &Tuning::chain_margin}, {"MI_FFT_WAVES", &Tuning::fft_waves},
+    {"MI_FFT_PERSISTENT", &Tuning::fft_persistent}, {"MI_FFT_PREFETCH", &Tuning::fft_prefetch},
+    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split},
+    {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
+    {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_FFT_COL_TILE", &Tuning::fft_col_tile},
+};
+Tuning& tuning_rw()
+{
+    static Tuning t = [] {                 // the environment is read here, once per process
+        Tuning v;
+        for (const Knob& k : KNOBS) {
+            const char* e = getenv(k.name);
+            if (e && *e) v.*(k.field) = atoi(e);
+        }
+        return v;
+    }();
+    return t;
+}
+}  // namespace
+
+const Tuning& tuning() { return tuning_rw(); }
+
+bool set_tuning(const char* name, int value)
+{
+    for (const Knob& k : KNOBS)
+        if (name && strcmp(name, k.name) == 0) {
+            // a plain int store: callers change knobs between launches, not concurrently with them
+            tuning_rw().*(k.field) = value;
+            return true;
+        }
+    return false;
+}
+
 // generateGaussianKernal, reference kernels/imageTools.cu:362-385: expf of a float argument,
 // division by the double 2*pi*sigma^2, narrowed to float, summed in float in i-major order,
 // every entry divided by the sum.
@@ -83,8 +121,8 @@ static int check_filter(int filter, int w, int h, int ksize, float sigma)
     case MI_FILTER_SOBEL: return MI_OK;
     case MI_FILTER_GAUSSIAN:
     case MI_FILTER_GAUSSIAN_DIRECT:
-        if (ksize < 1 || ksize % 2 == 0 || ksize > 15)
-            return fail(MI_ERR_BAD_KERNEL_SIZE, "Gaussian kernel size must be odd, in [1,15] (got %d)", ksize);
+        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE)
+            return fail(MI_ERR_BAD_KERNEL_SIZE, "Gaussian kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, ksize);
         if (!(sigma > 0.0f) || !isfinite(sigma)) return fail(MI_ERR_INVALID_ARG, "sigma must be positive and finite");
         return MI_OK;
     case MI_FILTER_MEAN:
@@ -110,7 +148,7 @@ static int run_frames(int filter, const void* in, void* out, int w, int h, int b
     // kernel size 1 is the identity on the write set; the generic paths handle it
     FilterArgs a;
     a.filter = filter;
-    if (filter == MI_FILTER_GAUSSIAN && ksize == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    if (filter == MI_FILTER_GAUSSIAN && (ksize == 1 || ksize > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
     a.in = in; a.out = out; a.w = w; a.h_total = h; a.batch = batch;
     a.in_row0 = 0; a.in_rows = h; a.y_begin = 0; a.y_end = h;
     a.ksize = ksize; a.sigma = sigma; a.stream = (hipStream_t)stream;
@@ -188,6 +226,11 @@ extern "C" {
 
 int mi_version(void) { return 100; }
 const char* mi_last_error(void) { return g_err; }
+
+int mi_debug_set_tuning(const char* name, int value)
+{
+    return set_tuning(name, value) ? MI_OK : fail(MI_ERR_INVALID_ARG, "unknown tuning knob %s", name ? name : "(null)");
+}
 
 int mi_device_count(void)
 {
@@ -272,7 +315,7 @@ int mi_filter_strip_u8x4_dev(int filter, const void* d_in, void* d_out, int w, i
         return fail(MI_ERR_OVERLAP, "device-tier in/out buffers overlap");
     FilterArgs a;
     a.filter = filter;
-    if (filter == MI_FILTER_GAUSSIAN && param_i == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    if (filter == MI_FILTER_GAUSSIAN && (param_i == 1 || param_i > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
     a.in = d_in; a.out = d_out; a.w = w; a.h_total = h_total; a.batch = 1;
     a.in_row0 = in_row0; a.in_rows = in_rows; a.y_begin = y_begin; a.y_end = y_end;
     a.ksize = param_i; a.sigma = param_f; a.stream = (hipStream_t)stream;

@@ -365,12 +365,12 @@ __global__ __launch_bounds__(256) void fft_small_kernel(const c2* __restrict__ i
 }
 
 // ---------------------------------------------------------------- host side
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
+// The twiddle table of the current device is filled once, by the first FFT call on that device, and
+// that call blocks until the fill has completed before any stream is told the table exists: a first
+// call on another stream or thread either waits on the mutex or finds a finished table (it used to
+// be marked ready as soon as the fill was enqueued, and a second stream could read it half written).
+// Under stream capture nothing may block and the fill would only be recorded, so it is recorded
+// with that graph (every replay fills the table again, harmlessly) and the table stays "not ready".
 static int ensure_twiddles(hipStream_t s)
 {
     static std::mutex mu;
@@ -378,45 +378,69 @@ static int ensure_twiddles(hipStream_t s)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_status(e, "hipGetDevice");
+    if (dev < 0 || dev >= 64) return fail(MI_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lock(mu);
-    if (dev < 0 || dev >= 64 || !ready[dev]) {
-        // stream-ordered: the transform kernels that follow on `s` see the table; the first
-        // call on a device must not race with FFT calls on other streams of that device
-        // under stream capture the fill is only recorded (it then runs with every replay of that graph):
-        // the table does not exist yet, so the next eager call still has to fill it
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-        twiddle_init_kernel<<<TW_N / 256, 256, 0, s>>>();
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_status(e, "twiddle table init");
-        if (dev >= 0 && dev < 64 && cap == hipStreamCaptureStatusNone) ready[dev] = true;
-    }
+    if (ready[dev]) return MI_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    twiddle_init_kernel<<<TW_N / 256, 256, 0, s>>>();
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_status(e, "twiddle table init");
+    if (cap != hipStreamCaptureStatusNone) return MI_OK;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return hip_status(e, "twiddle table init");
+    ready[dev] = true;
     return MI_OK;
 }
+
+// hipFuncSetAttribute and the occupancy query are per device: once per (kernel, device).
+struct PerDeviceAttr {
+    std::mutex mu;
+    bool done[64] = {};
+    hipError_t err[64] = {};
+    int blocks_per_cu[64] = {};
+    template <class Init>
+    hipError_t get(int* blocks, Init init)
+    {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[dev]) {
+            blocks_per_cu[dev] = 1;
+            err[dev] = init(&blocks_per_cu[dev]);
+            done[dev] = true;
+        }
+        if (blocks) *blocks = blocks_per_cu[dev];
+        return err[dev];
+    }
+};
 
 template <int N, int LPB, bool COL, bool TW, bool PREFETCH>
 static int launch_lines_pf(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     constexpr int threads = (N / 16) * LPB;
     constexpr size_t lds = ((size_t)LPB * (N + N / 16) + Plan<N>::tw_total + (TW ? 2 * N : 0)) * sizeof(c2);
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    static int blocks_per_cu = 1;
+    static PerDeviceAttr attr;
     static_assert(lds <= 160 * 1024, "a block's lines and twiddle tables must fit the CU's LDS");
-    std::call_once(once, [] {
+    int blocks_per_cu = 1;
+    const hipError_t attr_err = attr.get(&blocks_per_cu, [](int* blocks) {
+        hipError_t e = hipSuccess;
         if (lds > 64 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)fft_lines_kernel<N, LPB, COL, TW, PREFETCH>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute((const void*)fft_lines_kernel<N, LPB, COL, TW, PREFETCH>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int n = 0;
-        if (attr_err == hipSuccess &&
+        if (e == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fft_lines_kernel<N, LPB, COL, TW, PREFETCH>, threads, lds) == hipSuccess && n > 0)
-            blocks_per_cu = n;
+            *blocks = n;
+        return e;
     });
     if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
     const i64 blocks = ((i64)g.total_lines + LPB - 1) / LPB;
     // persistent blocks: every CU keeps its full complement, each walks several line groups
-    const i64 resident = (i64)256 * blocks_per_cu * std::max(1, env_int("MI_FFT_WAVES", 1));
-    const int grid = (int)std::min<i64>(blocks, env_int("MI_FFT_PERSISTENT", 1) ? resident : blocks);
+    const i64 resident = (i64)256 * blocks_per_cu * std::max(1, tuning().fft_waves);
+    const int grid = (int)std::min<i64>(blocks, tuning().fft_persistent ? resident : blocks);
     if (blocks > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "fft launch too large");
     fft_lines_kernel<N, LPB, COL, TW, PREFETCH><<<grid, threads, lds, s>>>(in, out, g, bytes);
     return hip_status(hipGetLastError(), "fft kernel launch");
@@ -427,7 +451,7 @@ static int launch_lines_tw(const c2* in, c2* out, const FftGeo& g, u32 bytes, hi
 {
     // 1024-lane blocks have 128 registers per lane: no room to hold the next group's points
     if constexpr ((N / 16) * LPB <= 512) {
-        if (env_int("MI_FFT_PREFETCH", 1) && (!TW || g.tw_uniform)) return launch_lines_pf<N, LPB, COL, TW, true>(in, out, g, bytes, s);
+        if (tuning().fft_prefetch && (!TW || g.tw_uniform)) return launch_lines_pf<N, LPB, COL, TW, true>(in, out, g, bytes, s);
     }
     return launch_lines_pf<N, LPB, COL, TW, false>(in, out, g, bytes, s);
 }
@@ -482,7 +506,7 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
     // same group back to back), so a pass finds the previous pass's output on die instead of
     // re-reading it from HBM.  MI_FFT_GROUP_MIB=0 makes every pass sweep the whole batch.
     const i64 plane = (i64)rows * cols;
-    const i64 budget = (i64)env_int("MI_FFT_GROUP_MIB", 300) << 20;
+    const i64 budget = (i64)tuning().fft_group_mib << 20;
     int group = budget <= 0 ? batch : (int)std::max<i64>(1, std::min<i64>(batch, budget / (plane * 8)));
     group = (int)std::max<i64>(1, std::min<i64>(group, ((i64)1 << 30) / ((i64)std::max(rows, 64 * cols))));
     group = (int)std::max<i64>(1, std::min<i64>(group, (((i64)1 << 31) - 1) / (plane * 8)));   // buffer offsets stay below 2^31
@@ -495,7 +519,7 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
     // In place, the split needs one plane of scratch (`tmp`): A writes there, B works there, the
     // row pass brings the plane back; without it the single long-column pass is used (half speed).
     const bool via_tmp = in == out && tmp != nullptr;
-    const bool split = (in != out || via_tmp) && rows >= 1024 && env_int("MI_FFT_SPLIT", 1);
+    const bool split = (in != out || via_tmp) && rows >= 1024 && tuning().fft_split;
     if (split && via_tmp) group = 1;
     for (int b0 = 0; b0 < batch; b0 += group) {
         const int nb = std::min(group, batch - b0);
@@ -747,17 +771,16 @@ static int launch_blue_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_str
     constexpr int threads = (M / 16) * LPB;
     constexpr size_t lds = ((size_t)LPB * (M + M / 16) + Plan<M>::tw_total) * sizeof(c2);
     static_assert(lds <= 160 * 1024, "a block's lines and twiddle tables must fit the CU's LDS");
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        if (lds > 64 * 1024)
-            attr_err = hipFuncSetAttribute((const void*)blue_lines_kernel<M, LPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static PerDeviceAttr attr;
+    const hipError_t attr_err = attr.get(nullptr, [](int*) {
+        return lds > 64 * 1024 ? hipFuncSetAttribute((const void*)blue_lines_kernel<M, LPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipSuccess;
     });
     if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
     const i64 blocks = ((i64)nlines + LPB - 1) / LPB;
     // persistent blocks, two per CU (measured: 5-8 % faster than one block per group; holding the next
     // group's points in a second register set, as the power-of-two kernel does, was 30 % slower here)
-    const int grid = (int)std::min<i64>(blocks, 256 * (i64)std::max(1, env_int("MI_FFT_CHIRPZ_BLOCKS_PER_CU", 2)));
+    const int grid = (int)std::min<i64>(blocks, 256 * (i64)std::max(1, tuning().fft_chirpz_blocks_per_cu));
     blue_lines_kernel<M, LPB><<<grid, threads, lds, s>>>(src, src_stride, dst, dst_stride, nlines, n, t.chirp, t.bhat, inverse);
     return hip_status(hipGetLastError(), "chirp-z kernel launch");
 }
@@ -769,7 +792,7 @@ static int any_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int
     if (t.m == 0) return pow2_lines(src, src_stride, dst, dst_stride, nlines, n, dir, s);
     const int m_log2 = __builtin_ctz(t.m);
     const int inverse = dir > 0;
-    if (env_int("MI_FFT_FUSED_CHIRPZ", 1)) {
+    if (tuning().fft_fused_chirpz) {
         switch (t.m) {     // lines per block as in launch_pass's row pass
         case 16: return launch_blue_lines<16, 64>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
         case 32: return launch_blue_lines<32, 64>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
@@ -854,7 +877,7 @@ int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, i
     // Planes go through in groups: the transposed copies of a group live in the workspace's plane and
     // (when the fused kernels run, which need no padded lines) its padded-line area -- at least three
     // planes together.  With the separate kernels (MI_FFT_FUSED_CHIRPZ=0, or m = 8) one plane at a time.
-    const bool fused = env_int("MI_FFT_FUSED_CHIRPZ", 1) && (L.mc == 0 || L.mc >= 16) && (L.mr == 0 || L.mr >= 16);
+    const bool fused = tuning().fft_fused_chirpz && (L.mc == 0 || L.mc >= 16) && (L.mr == 0 || L.mr >= 16);
     const int group = fused ? (int)std::min<i64>(std::min<i64>(batch, 65535), std::max<i64>(1, (L.plane_t + L.pad) / plane)) : 1;
     for (int b = 0; b < batch; b += group) {
         const int nb = std::min(group, batch - b);

@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
 // ============================================================================ generic kernels
 // One thread per pixel, taps read one by one through the cache: the fallback for kernel sizes
 // without a specialised kernel, and the bit-exact "direct" Gaussian.
-struct Weights2D { float w[15 * 15]; };
+struct Weights2D { float w[MI_MAX_KERNEL_SIZE * MI_MAX_KERNEL_SIZE]; };   // 3844 B: fits the 4 KiB of kernel arguments
 
 MI_DEV u32 tap_px(const u32* __restrict__ in, const Geo& g, i64 f)
 {
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void mean_tile_kernel(const u32* __restrict__ 
     }
 }
 
-// The direct (reference-order, bit-exact) Gaussian for kernel sizes 9..15: too many taps for the
+// The direct (reference-order, bit-exact) Gaussian for kernel sizes 9..31: too many taps for the
 // wave march's registers, so one block per 64 x 16 output tile, with the tile and its border in
 // LDS like mean_tile_kernel.  A lane owns 4 horizontally adjacent outputs: every pixel of a window
 // row is read and widened once and feeds up to four accumulations, each of which still runs
@@ -1186,12 +1186,6 @@ __global__ __launch_bounds__(256) void synth_kernel(u32* __restrict__ out, uint6
 }
 
 // ============================================================================ launcher
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
 static int grid_cap() { return 256 * 8; }  // 256 CUs x 8 blocks of 256 threads
 
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
@@ -1327,13 +1321,13 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     // margin lanes per side: one is enough for the chain's 4-pixel reach; two make the strips 240
     // pixels wide, whose rows start on 64-byte boundaries (+3 % measured), and are taken when that
     // costs no extra strip (3840 = 16 x 240, 1920 = 8 x 240)
-    int mrg = env_int("MI_CHAIN_MARGIN", 0);
+    int mrg = tuning().chain_margin;
     if (mrg != 1 && mrg != 2) mrg = (W + 239) / 240 <= (W + 247) / 248 ? 2 : 1;
     const int outw = 4 * (64 - 2 * mrg);
     g.strips = (W + outw - 1) / outw;
     // tall bands amortise the 8 extra rows a band runs through the early stages (measured flat
     // between 24 and 36 rows, slower beyond); shrink them only to fill the machine
-    int rpb = env_int("MI_CHAIN_ROWS_PER_BAND", 0);
+    int rpb = tuning().chain_rows_per_band;
     if (rpb <= 0) {
         rpb = 30;
         // (small batches: measured on 1, 2 and 4 4K frames and on single 1080p and 675x900 frames)
@@ -1416,7 +1410,7 @@ int launch_filter(const FilterArgs& a)
         }
         return hip_status(hipGetLastError(), "tiled mean kernel launch");
     }
-    if (direct && a.ksize >= 9 && a.ksize <= 15) {
+    if (direct && a.ksize >= 9 && a.ksize <= MI_MAX_KERNEL_SIZE) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         Weights2D wt;
         gaussian_kernel_2d(a.ksize, a.sigma, wt.w);
@@ -1430,10 +1424,11 @@ int launch_filter(const FilterArgs& a)
                 const u32* pin = in + (i64)f0 * in_frame;
                 u32* pout = out + (i64)f0 * out_frame;
                 switch (a.ksize) {
-                case 9: gauss_direct_tile_kernel<9><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
-                case 11: gauss_direct_tile_kernel<11><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
-                case 13: gauss_direct_tile_kernel<13><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
-                default: gauss_direct_tile_kernel<15><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+#define MI_TILE_CASE(K) case K: gauss_direct_tile_kernel<K><<<grid, 256, 0, a.stream>>>(pin, pout, gg, wt); break;
+                MI_TILE_CASE(9) MI_TILE_CASE(11) MI_TILE_CASE(13) MI_TILE_CASE(15) MI_TILE_CASE(17) MI_TILE_CASE(19)
+                MI_TILE_CASE(21) MI_TILE_CASE(23) MI_TILE_CASE(25) MI_TILE_CASE(27) MI_TILE_CASE(29) MI_TILE_CASE(31)
+#undef MI_TILE_CASE
+                default: return fail(MI_ERR_BAD_KERNEL_SIZE, "direct Gaussian: kernel size %d", a.ksize);
                 }
             }
         }
@@ -1471,7 +1466,7 @@ int launch_filter(const FilterArgs& a)
     // at 4-6 rows per band, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
     // are shared with the neighbouring band through L2 (see March), not re-fetched from HBM.
     // A taller band amortises the row pass of a wide Gaussian over more output rows.
-    int rpb = env_int("MI_ROWS_PER_BAND", 0);
+    int rpb = tuning().rows_per_band;
     if (rpb <= 0) {
         const int r = (a.filter == MI_FILTER_GAUSSIAN || a.filter == MI_FILTER_MEAN || direct_march) ? a.ksize / 2 : 1;
         rpb = r == 1 ? 6 : std::min(10 * r, 64);

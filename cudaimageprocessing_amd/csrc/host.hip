@@ -27,9 +27,12 @@ struct Slot {
     hipEvent_t done = nullptr;
 };
 
+// One pipe (and one spectral scratch, below) per device: host-tier calls from threads that drive
+// different GPUs neither serialise on each other nor free each other's buffers.
+constexpr int MAX_DEV = 64;
+
 struct HostPipe {
     std::mutex mu;
-    int device = -1;
     size_t cap_in = 0, cap_out = 0, cap_dev = 0;
     static constexpr int NSLOT = 3;
     Slot slot[NSLOT];
@@ -45,15 +48,12 @@ struct HostPipe {
             s = Slot();
         }
         cap_in = cap_out = cap_dev = 0;
-        device = -1;
     }
 
+    // called with this pipe's device current
     hipError_t reserve(size_t in_bytes, size_t out_bytes, size_t dev_bytes)
     {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev != device) { release(); device = dev; }
+        hipError_t e = hipSuccess;
         for (Slot& s : slot) {
             if (!s.stream && (e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return e;
             if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
@@ -87,53 +87,70 @@ struct HostPipe {
     }
 };
 
-HostPipe g_pipe;
+HostPipe g_pipes[MAX_DEV];
 
-// device scratch of the host-tier spectral calls (grow-only, one device at a time)
+// device scratch of the host-tier spectral calls (grow-only, one per device)
 struct Scratch {
     std::mutex mu;
-    int device = -1;
     void* ptr = nullptr;
     size_t cap = 0;
     HostScratch::TableKey tables{nullptr, 0, 0};
     void release()
     {
         if (ptr) (void)hipFree(ptr);
-        ptr = nullptr; cap = 0; device = -1;
+        ptr = nullptr; cap = 0;
         tables = HostScratch::TableKey{nullptr, 0, 0};
     }
 };
 
-Scratch g_scratch;
+Scratch g_scratches[MAX_DEV];
 
 struct Rows { int lo, hi; };
 
+int current_device(int* dev)
+{
+    const hipError_t e = hipGetDevice(dev);
+    if (e != hipSuccess) return hip_status(e, "hipGetDevice");
+    if (*dev < 0 || *dev >= MAX_DEV) return fail(MI_ERR_UNSUPPORTED, "device ordinal %d out of range", *dev);
+    return MI_OK;
+}
+
 }  // namespace
 
+// Frees every device's cached buffers (the caller's current device is restored).
 int host_release()
 {
-    std::lock_guard<std::mutex> lock(g_pipe.mu);
-    g_pipe.release();
-    std::lock_guard<std::mutex> lock2(g_scratch.mu);
-    g_scratch.release();
+    int keep = -1;
+    const bool have = hipGetDevice(&keep) == hipSuccess;
+    for (int d = 0; d < MAX_DEV; d++) {
+        std::lock_guard<std::mutex> lock(g_pipes[d].mu);
+        std::lock_guard<std::mutex> lock2(g_scratches[d].mu);
+        const bool used = g_pipes[d].slot[0].stream || g_pipes[d].cap_dev || g_scratches[d].ptr;
+        if (!used) continue;
+        (void)hipSetDevice(d);
+        g_pipes[d].release();
+        g_scratches[d].release();
+    }
+    if (have) (void)hipSetDevice(keep);
     return MI_OK;
 }
 
 int host_scratch(size_t bytes, HostScratch* out)
 {
-    out->lock = std::unique_lock<std::mutex>(g_scratch.mu);
     out->ptr = nullptr;
     int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return hip_status(e, "host-tier scratch");
-    if (dev != g_scratch.device || bytes > g_scratch.cap) {
-        g_scratch.release();
-        if ((e = hipMalloc(&g_scratch.ptr, bytes)) != hipSuccess) return hip_status(e, "host-tier scratch");
-        g_scratch.cap = bytes;
-        g_scratch.device = dev;
+    const int rc = current_device(&dev);
+    if (rc) return rc;
+    Scratch& sc = g_scratches[dev];
+    out->lock = std::unique_lock<std::mutex>(sc.mu);
+    if (bytes > sc.cap) {
+        sc.release();
+        const hipError_t e = hipMalloc(&sc.ptr, bytes);
+        if (e != hipSuccess) return hip_status(e, "host-tier scratch");
+        sc.cap = bytes;
     }
-    out->ptr = g_scratch.ptr;
-    out->tables = &g_scratch.tables;
+    out->ptr = sc.ptr;
+    out->tables = &sc.tables;
     return MI_OK;
 }
 
@@ -151,14 +168,17 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     const int n_chunks = (h + chunk - 1) / chunk;
     const size_t in_rows_max = (size_t)std::min(h, chunk + 2 * halo_sum);
 
-    std::lock_guard<std::mutex> lock(g_pipe.mu);
-    hipError_t e = g_pipe.reserve(in_rows_max * pitch, (size_t)chunk * pitch, in_rows_max * pitch);
+    int device = 0;
+    int rc = current_device(&device);
+    if (rc) return rc;
+    HostPipe& pipe = g_pipes[device];
+    std::lock_guard<std::mutex> lock(pipe.mu);
+    hipError_t e = pipe.reserve(in_rows_max * pitch, (size_t)chunk * pitch, in_rows_max * pitch);
     if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
 
     constexpr int NSLOT = HostPipe::NSLOT;
     std::vector<Rows> need(n_ops + 1);
     std::vector<Rows> out_rows(n_chunks);
-    int rc = MI_OK;
 
     // The unloading side: chunk c leaves its slot's pinned buffer for `out` once the device is done
     // with it AND the main thread has staged chunk c+1 -- when `out` aliases `in`, chunk c+1's input
@@ -172,7 +192,7 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
                 if (abort_flag.load(std::memory_order_acquire)) return;
                 std::this_thread::yield();
             }
-            Slot& s = g_pipe.slot[c % NSLOT];
+            Slot& s = pipe.slot[c % NSLOT];
             const hipError_t err = hipEventSynchronize(s.done);
             if (err != hipSuccess) { unload_err = err; abort_flag.store(true, std::memory_order_release); return; }
             const Rows r = out_rows[c];
@@ -182,12 +202,10 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     };
     // one chunk: nothing to overlap, stay on this thread
     std::thread helper;
-    int device = 0;
-    (void)hipGetDevice(&device);
     if (n_chunks > 1) helper = std::thread([&] { (void)hipSetDevice(device); unload_all(); });
 
     for (int c = 0; c < n_chunks && rc == MI_OK && e == hipSuccess; c++) {
-        Slot& s = g_pipe.slot[c % NSLOT];
+        Slot& s = pipe.slot[c % NSLOT];
         // the slot's previous occupant (chunk c - NSLOT) must have left its pinned output buffer
         while (unloaded.load(std::memory_order_acquire) < c - NSLOT + 1 && !abort_flag.load(std::memory_order_acquire))
             std::this_thread::yield();
@@ -205,7 +223,7 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
         for (int k = 0; k < n_ops && rc == MI_OK && e == hipSuccess; k++) {
             FilterArgs a;
             a.filter = ops[k].filter;
-            if (a.filter == MI_FILTER_GAUSSIAN && ops[k].ksize == 1) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+            if (a.filter == MI_FILTER_GAUSSIAN && (ops[k].ksize == 1 || ops[k].ksize > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
             a.in = s.dev[cur]; a.out = s.dev[cur ^ 1]; a.w = w; a.h_total = h; a.batch = 1;
             a.in_row0 = need[k].lo; a.in_rows = need[k].hi - need[k].lo;
             a.y_begin = need[k + 1].lo; a.y_end = need[k + 1].hi;
@@ -224,7 +242,7 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     if (rc == MI_OK && e == hipSuccess && unload_err != hipSuccess) e = unload_err;
     if (rc != MI_OK || e != hipSuccess) {
         // leave nothing in flight that still points at the staging buffers
-        for (Slot& s : g_pipe.slot) if (s.stream) (void)hipStreamSynchronize(s.stream);
+        for (Slot& s : pipe.slot) if (s.stream) (void)hipStreamSynchronize(s.stream);
     }
     if (rc) return rc;
     return hip_status(e, "host-tier filter pipeline");

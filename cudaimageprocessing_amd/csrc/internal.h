@@ -15,6 +15,25 @@ int fail(int code, const char* fmt, ...);
 // Maps a hipError_t to the ABI's return value (0 or the positive error code), recording it.
 int hip_status(hipError_t e, const char* what);
 
+// Tuning knobs.  The environment (MI_ROWS_PER_BAND, ...) is read ONCE per process, on first use; a
+// launch only reads these integers.  mi_debug_set_tuning changes one at run time (tests, sweeps).
+struct Tuning {
+    int rows_per_band = 0;        // MI_ROWS_PER_BAND: rows a wave marches over (0 = per-filter default)
+    int chain_rows_per_band = 0;  // MI_CHAIN_ROWS_PER_BAND
+    int chain_margin = 0;         // MI_CHAIN_MARGIN: margin lanes per side of the fused chain's strips
+    int fft_waves = 1;            // MI_FFT_WAVES
+    int fft_persistent = 1;       // MI_FFT_PERSISTENT
+    int fft_prefetch = 1;         // MI_FFT_PREFETCH
+    int fft_group_mib = 300;      // MI_FFT_GROUP_MIB: planes per Infinity-Cache group
+    int fft_split = 1;            // MI_FFT_SPLIT
+    int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
+    int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
+    int fft_col_tile = 1;         // MI_FFT_COL_TILE: single-pass column transform of tall planes in LDS tiles
+};
+const Tuning& tuning();
+// name: the environment variable's name; returns false for an unknown name
+bool set_tuning(const char* name, int value);
+
 // One filter launch over a (strip of a) batch of frames; see Geo in common.h for the meaning
 // of the row arguments.  All pointers are device pointers.
 struct FilterArgs {

@@ -183,16 +183,23 @@ void test_transforms(Report& rep)
         std::vector<float> x(2 * n), f(2 * n), back(2 * n);
         for (size_t i = 0; i < n; i++) { x[2 * i] = (float)((i * 37u + 11u) % 256u); x[2 * i + 1] = (float)((i * 91u) % 64u) - 32.f; }
         size_t ws_bytes = 0;
-        RUN(mi_fft2d_workspace_bytes(c.rows, c.cols, &ws_bytes));
-        void *d_x = nullptr, *d_f = nullptr, *d_ws = nullptr;
-        if (hipMalloc(&d_x, n * 8) != hipSuccess || hipMalloc(&d_f, n * 8) != hipSuccess ||
-            (ws_bytes && hipMalloc(&d_ws, ws_bytes) != hipSuccess)) { rep.fail("hipMalloc in transform test"); return; }
+        if (mi_fft2d_workspace_bytes(c.rows, c.cols, &ws_bytes) != MI_OK) {
+            rep.fail("fft2d %dx%d: workspace query failed: %s", c.rows, c.cols, mi_last_error());
+            continue;
+        }
+        // device buffers are freed on every path out of this block
+        struct DevBuf {
+            void* p = nullptr;
+            ~DevBuf() { if (p) (void)hipFree(p); }
+        } bx, bf, bws;
+        if (hipMalloc(&bx.p, n * 8) != hipSuccess || hipMalloc(&bf.p, n * 8) != hipSuccess ||
+            (ws_bytes && hipMalloc(&bws.p, ws_bytes) != hipSuccess)) { rep.fail("hipMalloc in transform test"); return; }
+        void *d_x = bx.p, *d_f = bf.p, *d_ws = bws.p;
         bool ok = hipMemcpy(d_x, x.data(), n * 8, hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && mi_fft2d_c2c_f32_ws_dev(d_x, d_f, c.rows, c.cols, 1, MI_FFT_FORWARD, d_ws, ws_bytes, nullptr) == MI_OK;
         ok = ok && hipMemcpy(f.data(), d_f, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
         ok = ok && mi_fft2d_c2c_f32_ws_dev(d_f, d_f, c.rows, c.cols, 1, MI_FFT_INVERSE, d_ws, ws_bytes, nullptr) == MI_OK;
         ok = ok && hipMemcpy(back.data(), d_f, n * 8, hipMemcpyDeviceToHost) == hipSuccess;
-        (void)hipFree(d_x); (void)hipFree(d_f); if (d_ws) (void)hipFree(d_ws);
         if (!ok) { rep.fail("fft2d %dx%d: call failed: %s", c.rows, c.cols, mi_last_error()); continue; }
         // X[0,0] = sum x;  Parseval;  inverse(forward(x)) = N x
         double sr = 0, si = 0, ex = 0, ef = 0, err = 0;

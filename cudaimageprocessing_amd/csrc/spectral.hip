@@ -1,6 +1,7 @@
 // spectral.hip -- the pointwise kernels of the reference's FFT demo path
 // (imageFFTImageGenerate, kernels/imageTools.cu:633-791) and the normalise helpers (:416-471).
 // The 2-D transform itself lives in fft.hip.
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -326,12 +327,42 @@ __global__ __launch_bounds__(256) void mag_mask_kernel(f32x2v* __restrict__ d, i
         if (mag2_bits(d[i]) < thr) d[i] = f32x2v{0.f, 0.f};
 }
 
+// The histograms live in a static device array (32 KiB per GPU), so the selection allocates
+// nothing and never pays hipFree's device-wide synchronisation.  Calls on one device take turns
+// on it (SelHist holds that device's mutex for the length of the call).
+static __device__ __align__(256) u32 g_sel_hist[SEL_MAX_PLANES * SEL_BINS];
+
+struct SelHist {
+    std::unique_lock<std::mutex> lock;
+    u32* ptr = nullptr;
+    int acquire()
+    {
+        static std::mutex mu[64];
+        static u32* dev_ptr[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return hip_status(e, "hipGetDevice");
+        if (dev < 0 || dev >= 64) return fail(MI_ERR_UNSUPPORTED, "device ordinal %d out of range", dev);
+        lock = std::unique_lock<std::mutex>(mu[dev]);
+        if (!dev_ptr[dev]) {
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_sel_hist));
+            if (e != hipSuccess) return hip_status(e, "hipGetSymbolAddress(g_sel_hist)");
+            dev_ptr[dev] = (u32*)p;
+        }
+        ptr = dev_ptr[dev];
+        return MI_OK;
+    }
+};
+
 // `planes` spectra of n values each, back to back, each keeping its own `keep` largest.
 // Blocking: reads three histograms per plane back on the host (one read-back per level for all planes).
 int spectrum_keep_top(void* data, size_t n, size_t keep, int planes, hipStream_t s)
 {
     if (keep >= n || planes <= 0) return MI_OK;
     int rc = MI_OK;
+    SelHist sel;
+    if (keep != 0 && (rc = sel.acquire()) != MI_OK) return rc;
     for (int p0 = 0; p0 < planes && rc == MI_OK; p0 += SEL_MAX_PLANES) {
         const int np = std::min(SEL_MAX_PLANES, planes - p0);
         f32x2v* base = (f32x2v*)data + (size_t)p0 * n;
@@ -343,9 +374,8 @@ int spectrum_keep_top(void* data, size_t n, size_t keep, int planes, hipStream_t
             rc = hip_status(hipGetLastError(), "spectrum_keep_top");
             continue;
         }
-        u32* d_hist = nullptr;
-        hipError_t e = hipMalloc((void**)&d_hist, (size_t)np * SEL_BINS * sizeof(u32));
-        if (e != hipSuccess) return hip_status(e, "spectrum histogram");
+        u32* d_hist = sel.ptr;
+        hipError_t e = hipSuccess;
         std::vector<u32> hist((size_t)np * SEL_BINS);
         // digits, most significant first: (shift, width)
         const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
@@ -374,7 +404,6 @@ int spectrum_keep_top(void* data, size_t n, size_t keep, int planes, hipStream_t
             mag_mask_kernel<<<grid, 256, 0, s>>>(base, (i64)n, prefix);   // after three levels the prefix is the threshold
             e = hipGetLastError();
         }
-        (void)hipFree(d_hist);
         rc = hip_status(e, "spectrum_keep_top");
     }
     return rc;

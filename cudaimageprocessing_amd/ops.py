@@ -123,6 +123,29 @@ def halo_rows(filter_id, ksize=3):
     return n
 
 
+def set_tuning(name, value):
+    """One tuning knob of the library (mi_debug_set_tuning; `name` = its environment variable's name)."""
+    check(lib().mi_debug_set_tuning(str(name).encode(), int(value)))
+
+
+class tuning:
+    """Context manager: `with ops.tuning(MI_ROWS_PER_BAND=8): ...`; `restore` gives the values to
+    put back afterwards (default: 0 = the library's own choice for the rows-per-band knobs)."""
+
+    def __init__(self, restore=None, **knobs):
+        self.knobs, self.restore = knobs, restore or {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.knobs:
+            set_tuning(k, self.restore.get(k, 0))
+        return False
+
+
 def synth(seed, w, h, batch=None, first_idx=0, device="cuda"):
     """Synthetic frames generated on the device (same stream of pixels as oracle synth)."""
     torch = _torch()
@@ -291,7 +314,9 @@ def imageSobelEdgeWrapper(returnImage, imageLoaded, width, height):
     check(lib().mi_sobel_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height), width, height))
 
 
-def imageGaussianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize, sigma, direct=False):
+def imageGaussianBlurWrapper(returnImage, imageLoaded, width, height, kernalSize, sigma, direct=True):
+    """The reference's wrapper: by default the reference's own k x k summation order (the same bytes
+    as upstream); direct=False takes the separable kernel (within 1 LSB)."""
     check(lib().mi_gaussian_u8x4(_host_img(imageLoaded, width, height), _host_img(returnImage, width, height),
                                  width, height, int(kernalSize), float(sigma),
                                  _lib.GAUSS_DIRECT if direct else _lib.GAUSS_SEPARABLE))

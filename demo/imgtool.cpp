@@ -172,7 +172,7 @@ int pixel_filter_id(const Op& op)
 {
     if (op.name == "gray") return MI_FILTER_GRAYSCALE;
     if (op.name == "sobel") return MI_FILTER_SOBEL;
-    if (op.name == "gauss") return MI_FILTER_GAUSSIAN;
+    if (op.name == "gauss") return MI_FILTER_GAUSSIAN_DIRECT;   // the same bytes as imageGaussianBlurWrapper (the reference's summation order)
     if (op.name == "mean") return MI_FILTER_MEAN;
     if (op.name == "median") return MI_FILTER_MEDIAN;
     return -1;

@@ -19,6 +19,7 @@ void imageLoadWrapper(unsigned char* image, uchar4* imageLoaded, size_t imgSize)
 void imageWriteWrapper(const char* filename, uchar4* pixels, int width, int height);
 void imageGrayScaleWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height);
 void imageSobelEdgeWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height);
+// The reference's k x k sum in its own order (bit-exact); kernalSize odd, 1..31 (upstream: any odd size).
 void imageGaussianBlurWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height, int kernalSize, float sigma);
 void imageMeanBlurWrapper(uchar4* returnImage, uchar4* imageLoaded, int width, int height);
 void imageFFTImageGenerate(uchar4* returnImage, uchar4* imageLoaded, int width, int height);

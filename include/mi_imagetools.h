@@ -55,6 +55,12 @@ const char *mi_last_error(void);
 /* Number of visible HIP devices (0 when there is none); never fails. */
 int mi_device_count(void);
 
+/* Tuning knobs (rows per band, FFT plane groups, ...; the list is in INTEGRATION.md).  Each has an
+ * environment variable of the same name, read once per process on first use; this call changes
+ * one at run time (tests and tuning sweeps; not meant to race with launches on other threads).
+ * Debug aid, not in the reference. */
+int mi_debug_set_tuning(const char *name, int value);
+
 /* ---------------------------------------------------------------- device tier
  * All device-tier filters process `batch` frames of w x h pixels stored back to back. */
 
@@ -72,7 +78,8 @@ int mi_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, vo
 /* imageGaussianBlur + generateGaussianKernal (imageTools.cu:287-311, 362-385).
  * mode MI_GAUSS_SEPARABLE: row pass then column pass with 1-D weights (max |delta| <= 1 LSB
  *   against the reference's direct 2-D sum, which truncates float->u8, imageTools.cu:306-308);
- * mode MI_GAUSS_DIRECT: the reference's k x k sum in its own order, bit-exact, slower. */
+ * mode MI_GAUSS_DIRECT: the reference's k x k sum in its own order, bit-exact, slower.
+ * kernel_size: odd, 1..MI_MAX_KERNEL_SIZE; sizes above 15 always take the direct form. */
 #define MI_GAUSS_SEPARABLE 0
 #define MI_GAUSS_DIRECT 1
 int mi_gaussian_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,
@@ -249,7 +256,9 @@ int mi_fft_highpass_batch_u8x4_dev(const void *d_in, void *d_out, int w, int h, 
 #define MI_COMPRESS_DEFAULT_KEEP 0.10f
 int mi_compress_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float keep_fraction);
 /* The selection step of mi_compress_u8x4 on a device spectrum of n complex values, in place.
- * Blocking (the threshold search reads three histograms back to the host). */
+ * Blocking (the threshold search reads three histograms back to the host and waits for `stream`
+ * each time); allocates nothing (its histograms are a static 32 KiB device array; calls on one
+ * device take turns on it). */
 int mi_spectrum_keep_top_dev(void *d_data, size_t n, size_t keep, void *stream);
 /* bool test() (declared at kernels/imageTools.h:19, never defined upstream): the library's
  * self-test -- known-answer checks of every filter, the transforms and the host pipeline on

@@ -79,13 +79,12 @@ def test_fft2d_any_size_matches_dft(dev, golden, rows, cols):
 
 
 @pytest.mark.parametrize("rows,cols,batch", [(90, 68, 7), (675, 900, 3), (17, 4095, 2), (64, 100, 5), (3, 5, 4), (100, 3, 2)])
-def test_fused_chirpz_equals_the_separate_kernels(dev, monkeypatch, rows, cols, batch):
+def test_fused_chirpz_equals_the_separate_kernels(dev, rows, cols, batch):
     """The one-kernel chirp-z line transform does the operations of the five separate kernels in the
     same order: bit-identical output, forward and inverse, for batches cut into plane groups."""
     x = torch.from_numpy(rand_plane(rows, cols, rows + 7 * cols, batch=batch)).to(dev)
-    monkeypatch.setenv("MI_FFT_FUSED_CHIRPZ", "0")
-    ref_f, ref_i = ops.fft2d(x).clone(), ops.fft2d(x, inverse=True).clone()
-    monkeypatch.setenv("MI_FFT_FUSED_CHIRPZ", "1")
+    with ops.tuning(MI_FFT_FUSED_CHIRPZ=0, restore={"MI_FFT_FUSED_CHIRPZ": 1}):
+        ref_f, ref_i = ops.fft2d(x).clone(), ops.fft2d(x, inverse=True).clone()
     assert torch.equal(ops.fft2d(x), ref_f)
     assert torch.equal(ops.fft2d(x, inverse=True), ref_i)
     y = x.clone()

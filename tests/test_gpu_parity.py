@@ -270,7 +270,7 @@ def test_fused_chain_batch(dev):
         assert torch.equal(fused[f], ops.fused_chain(frames[f].contiguous()))
 
 
-def test_decomposition_does_not_change_results(dev, monkeypatch):
+def test_decomposition_does_not_change_results(dev):
     """Band height (and with it the marching direction of every row) is a launch detail: every
     filter, the separable Gaussian included, gives bit-identical output for any choice."""
     img = ops.synth(77, 1920, 270)
@@ -280,16 +280,14 @@ def test_decomposition_does_not_change_results(dev, monkeypatch):
            "mean15": lambda t: ops.mean_blur(t, 15), "gauss11": lambda t: ops.gaussian_blur(t, 11, 2.0),
            "direct5": lambda t: ops.gaussian_blur(t, 5, 1.0, direct=True),
            "direct7": lambda t: ops.gaussian_blur(t, 7, 1.5, direct=True)}
-    monkeypatch.setenv("MI_ROWS_PER_BAND", "32")
-    monkeypatch.setenv("MI_CHAIN_ROWS_PER_BAND", "32")
-    ref = {k: fn(img).clone() for k, fn in fns.items()}
-    ref_chain = ops.fused_chain(img).clone()
-    for rpb in ("1", "2", "5", "7", "270"):
-        monkeypatch.setenv("MI_ROWS_PER_BAND", rpb)
-        monkeypatch.setenv("MI_CHAIN_ROWS_PER_BAND", rpb)
-        for k, fn in fns.items():
-            assert torch.equal(fn(img), ref[k]), (k, rpb)
-        assert torch.equal(ops.fused_chain(img), ref_chain), rpb
+    with ops.tuning(MI_ROWS_PER_BAND=32, MI_CHAIN_ROWS_PER_BAND=32):
+        ref = {k: fn(img).clone() for k, fn in fns.items()}
+        ref_chain = ops.fused_chain(img).clone()
+    for rpb in (1, 2, 5, 7, 270):
+        with ops.tuning(MI_ROWS_PER_BAND=rpb, MI_CHAIN_ROWS_PER_BAND=rpb):
+            for k, fn in fns.items():
+                assert torch.equal(fn(img), ref[k]), (k, rpb)
+            assert torch.equal(ops.fused_chain(img), ref_chain), rpb
 
 
 def test_large_batch_properties(dev):
@@ -359,10 +357,12 @@ def test_host_tier_wrappers(dev, golden, tmp_path):
     assert np.array_equal(out, golden.meanblur(img, 3))
     ops.imageMedianBlurWrapper(out, img, w, h, 3)
     assert np.array_equal(out, golden.medianblur(img, 3))
-    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0)        # the reference's call, main.cpp:41
-    assert np.abs(out.astype(np.int16) - golden.gaussian(img, 3, 7.0).astype(np.int16)).max() <= GAUSS_TOL
-    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0, direct=True)
+    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0)        # the reference's call, main.cpp:41: bit-exact by default
     assert np.array_equal(out, golden.gaussian(img, 3, 7.0))
+    ops.imageGaussianBlurWrapper(out, img, w, h, 3, 7.0, direct=False)
+    assert np.abs(out.astype(np.int16) - golden.gaussian(img, 3, 7.0).astype(np.int16)).max() <= GAUSS_TOL
+    ops.imageGaussianBlurWrapper(out, img, w, h, 21, 4.0)       # any odd size, like upstream (:478-502)
+    assert np.array_equal(out, golden.gaussian(img, 21, 4.0))
     # in place, as main.cpp:38-43 calls every wrapper with (img, img, ...)
     alias = img.copy()
     ops.imageSobelEdgeWrapper(alias, alias, w, h)
@@ -509,3 +509,24 @@ def test_device_tier_runs_under_graph_capture(dev):
     torch.cuda.synchronize()
     for got, ref in zip(outs + [spec, odd_out], want):
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("k,sigma", [(17, 3.0), (21, 4.0), (25, 2.0), (31, 6.0)])
+def test_gaussian_sizes_above_15_are_bit_exact(dev, golden, k, sigma):
+    """The reference takes any odd kernel size (imageTools.cu:478-502): 17..31 run the reference-order
+    k x k sum from LDS tiles whichever mode is asked for, bit-exact against the oracle, odd widths and
+    strips included."""
+    for w, h in ((197, 83), (256, 64)):
+        img = S.synth_image(k, w, h)
+        want = golden.gaussian(img, k, sigma)
+        d = torch.from_numpy(img).to(dev)
+        assert np.array_equal(ops.gaussian_blur(d, k, sigma, direct=True).cpu().numpy(), want)
+        assert np.array_equal(ops.gaussian_blur(d, k, sigma).cpu().numpy(), want)
+    halo = ops.halo_rows(_lib.FILTER_GAUSSIAN, k)
+    assert halo == k // 2 + 1
+    y0, y1 = 20, 47
+    lo, hi = max(0, y0 - halo), min(h, y1 + halo)
+    out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+    ops.filter_strip(_lib.FILTER_GAUSSIAN, d[lo:hi].contiguous(), out, w, h, lo, y0, y1, k, sigma)
+    assert np.array_equal(out.cpu().numpy(), want[y0:y1])
+

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times every filter kernel on a batch of 3840x2160 frames under different launch knobs
-(environment variables read by the library at each launch), interleaved in one process.
+(set through mi_debug_set_tuning), interleaved in one process.
 Usage: python tools/tune_filters.py [batch] ; prints GB/s (8 B/pixel algorithmic) per config."""
 import itertools
 import os
@@ -51,7 +51,7 @@ def sweep(filters, configs):
     for _ in range(ROUNDS):
         for i, cfg in enumerate(configs):
             for k, v in cfg.items():
-                os.environ[k] = str(v)
+                ops.set_tuning(k, v)
             for f, fn in filters.items():
                 res[(f, i)].append(timed(fn))
     print("config".ljust(44) + "".join(f"{f:>10s}" for f in filters))

@@ -5,6 +5,8 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 template <int KIND>
 __global__ __launch_bounds__(256) void bench(float* out, int iters, float seed)
@@ -35,6 +37,48 @@ __global__ __launch_bounds__(256) void bench(float* out, int iters, float seed)
             } else if (KIND == 5) {     // 2 cvt_f32_ubyte + ...
                 u32 x = __builtin_bit_cast(u32, a[k].x);
                 a[k].x = (float)(x & 0xffu) ; a[k].y = (float)((x >> 8) & 0xffu) + a[k].y;
+            } else if (KIND == 6) {     // 2 v_dot2_u32_u16
+                u32 x = __builtin_bit_cast(u32, a[k].x), y = __builtin_bit_cast(u32, a[k].y);
+                x = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, x), __builtin_bit_cast(u16x2, y), x, false);
+                y = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, y), __builtin_bit_cast(u16x2, x), y, false);
+                a[k].x = __builtin_bit_cast(float, x); a[k].y = __builtin_bit_cast(float, y);
+            } else if (KIND == 7) {     // 2 v_dot2_f32_f16
+                u32 x = __builtin_bit_cast(u32, a[k].x), y = __builtin_bit_cast(u32, a[k].y);
+                a[k].x = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, x), __builtin_bit_cast(h16x2, y), a[k].x, false);
+                a[k].y = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, y), __builtin_bit_cast(h16x2, x), a[k].y, false);
+            } else if (KIND == 8) {     // 2 v_sqrt_f32
+                a[k].x = __builtin_amdgcn_sqrtf(a[k].x);
+                a[k].y = __builtin_amdgcn_sqrtf(a[k].y);
+            } else if (KIND == 9) {     // 2 v_perm_b32
+                u32 x = __builtin_bit_cast(u32, a[k].x), y = __builtin_bit_cast(u32, a[k].y);
+                x = __builtin_amdgcn_perm(x, y, 0x05040100u);
+                y = __builtin_amdgcn_perm(y, x, 0x07060302u);
+                a[k].x = __builtin_bit_cast(float, x); a[k].y = __builtin_bit_cast(float, y);
+            } else if (KIND == 10) {    // 2 v_alignbit_b32
+                u32 x = __builtin_bit_cast(u32, a[k].x), y = __builtin_bit_cast(u32, a[k].y);
+                x = __builtin_amdgcn_alignbit(x, y, 16);
+                y = __builtin_amdgcn_alignbit(y, x, 8);
+                a[k].x = __builtin_bit_cast(float, x); a[k].y = __builtin_bit_cast(float, y);
+            } else if (KIND == 11) {    // v_cvt_u32_f32 + v_cvt_f32_u32
+                u32 x = (u32)a[k].x;
+                a[k].x = (float)(x + 1u) ; 
+            } else if (KIND == 13) {    // 2 v_pk_mad_u16
+                u16x2 x = __builtin_bit_cast(u16x2, a[k].x), y = __builtin_bit_cast(u16x2, a[k].y);
+                x = x * y + x;
+                y = y * x + y;
+                a[k].x = __builtin_bit_cast(float, x); a[k].y = __builtin_bit_cast(float, y);
+            } else if (KIND == 14) {    // 2 v_mad_u32_u24
+                u32 x = __builtin_bit_cast(u32, a[k].x), y = __builtin_bit_cast(u32, a[k].y);
+                x = (x & 0xffffffu) * (y & 0xffffffu) + x;
+                y = (y & 0xffffffu) * (x & 0xffffffu) + y;
+                a[k].x = __builtin_bit_cast(float, x); a[k].y = __builtin_bit_cast(float, y);
+            } else if (KIND == 15) {    // 1 v_cvt_pkrtz_f16_f32 + 1 v_pk_add_f16
+                h16x2 h = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(a[k].x, a[k].y));
+                h = h + __builtin_bit_cast(h16x2, a[k].y);
+                a[k].x = __builtin_bit_cast(float, h);
+            } else if (KIND == 16) {    // 2 v_floor_f32
+                a[k].x = __builtin_floorf(a[k].x + 0.5f);   // folds? keep the add out of the count if it stays
+                a[k].y = __builtin_floorf(a[k].y);
             }
         }
     }
@@ -64,6 +108,47 @@ void run(const char* name, int instr_per_iter, float* d)
     }
 }
 
+// sqrt-table shape: every lane reads a byte of a 64 KiB LDS table at a data-dependent address,
+// 4 lookups per iteration beside 8 fma (LDS issue beside VALU work)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lds_bench(float* out, int iters, u32 seed, int spread)
+{
+    __shared__ unsigned char tab[65536];
+    for (int i = threadIdx.x; i < 65536 / 4; i += BLOCK) ((u32*)tab)[i] = (u32)i * 2654435761u;
+    __syncthreads();
+    u32 x = seed + threadIdx.x * 7919u + blockIdx.x;
+    float acc = 0.f;
+    for (int i = 0; i < iters; i++) {
+        u32 s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x = x * 1664525u + 1013904223u;
+            s += tab[(x >> 8) & (u32)spread];
+        }
+        acc = __builtin_fmaf(acc, 0.999f, (float)s);
+    }
+    out[blockIdx.x * BLOCK + threadIdx.x] = acc;
+}
+
+void run_lds(float* d)
+{
+    const int iters = 20000;
+    for (int spread : {0xffff, 0x3ff}) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        lds_bench<768><<<512, 768>>>(d, 100, 1u, spread);
+        hipEventRecord(e0);
+        lds_bench<768><<<512, 768>>>(d, iters, 1u, spread);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        // 6 waves per SIMD (2 blocks of 12 waves per CU); cycles per lookup instruction per CU
+        const double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * 4 * 24);
+        printf("ds_read_u8 random (spread %5d) 6 waves/SIMD  %.3f ms  %.2f cycles/lookup-instr/CU\n", spread + 1, ms, cyc);
+    }
+}
+
 int main()
 {
     float* d;
@@ -74,6 +159,17 @@ int main()
     run<3>("v_pk_max/min_u16 (+add)", 24, d);
     run<4>("v_mov_b32_dpp x2", 16, d);
     run<5>("cvt_f32_ubyte x2 + add", 24, d);
+    run<6>("v_dot2_u32_u16 x2", 16, d);
+    run<7>("v_dot2_f32_f16 x2", 16, d);
+    run<8>("v_sqrt_f32 x2", 16, d);
+    run<9>("v_perm_b32 x2", 16, d);
+    run<10>("v_alignbit_b32 x2", 16, d);
+    run<11>("cvt_u32_f32+add+cvt_f32_u32", 24, d);
+    run<13>("v_pk_mul_lo_u16+v_pk_add_u16 x2", 32, d);
+    run<14>("v_mad_u32_u24 x2 (+and)", 16, d);
+    run<15>("cvt_pkrtz + pk_add_f16", 16, d);
+    run<16>("v_floor_f32 x2 (+add)", 24, d);
+    run_lds(d);
     hipFree(d);
     return 0;
 }

@@ -1307,11 +1307,20 @@ static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32
 #undef MI_L
 }
 
+// RowIO<1> addresses a band through 32-bit byte offsets from a descriptor that starts up to 16 rows
+// above the band; offsets at or above 2^31 double as the "do not load / do not store" sentinel.  A band
+// of rpb rows with every row the kernels touch around it (lead rows, halo and wrap rows, prefetched
+// rows: fewer than 48) must stay below that, or the launch takes the 64-bit-address policy (POL 0).
+static bool band_fits_buffer_offsets(int rpb, int W)
+{
+    return ((i64)rpb + 16 + 48) * W * 4 < 0x7FFFFF00LL;
+}
+
 int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float sigma, hipStream_t stream)
 {
     const u32* in = (const u32*)d_in;
     u32* out = (u32*)d_out;
-    const bool aligned = (W % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    bool aligned = (W % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
     Geo g;
     g.W = W; g.H = H; g.batch = batch;
     g.y_begin = 0; g.y_end = H;
@@ -1343,6 +1352,7 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     GaussW gw;
     gaussian_kernel_1d(5, sigma, gw.w);
     const int grid = (int)((total + 3) / 4);
+    aligned = aligned && band_fits_buffer_offsets(rpb, W);
     if (!aligned) chain_kernel<0, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
     else if (mrg == 2) chain_kernel<1, 2><<<grid, 256, 0, stream>>>(in, out, g, gw);
     else chain_kernel<1, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
@@ -1484,7 +1494,7 @@ int launch_filter(const FilterArgs& a)
     if (total > 0x7fffffff / 64) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
     g.total_waves = (int)total;
     g.xcd_remap = 1;
-    const int pol = aligned ? 1 : 0;
+    const int pol = (aligned && band_fits_buffer_offsets(rpb, W)) ? 1 : 0;
     const int grid = (int)((total + 3) / 4);
 
     switch (a.filter) {

@@ -2,6 +2,7 @@
 CPU oracle.  The transform itself replaces cuFFT (closed source, absent from the reference tree),
 so its oracle is the DFT definition evaluated in double precision: parity unpinned by reference
 vectors, tolerance 1e-5 relative L2 in fp32 as BASELINE.json states."""
+import os
 import numpy as np
 import pytest
 
@@ -316,3 +317,52 @@ def test_fft_highpass_image_pipeline(dev, golden):
         assert np.abs(p.cpu().numpy().real - ref_real[c]).max() < 2e-3
     assert np.abs(out.astype(np.int16) - ref_u8.astype(np.int16)).max() <= 1
     assert (out[..., 3] == 255).all()
+
+
+def test_first_fft_calls_on_two_streams_of_a_fresh_process(dev):
+    """The twiddle table is filled by the first FFT call on a device; a first call on a second stream
+    must not see a half-written table.  Needs a process that has not transformed anything yet."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch
+from cudaimageprocessing_amd import ops
+rng = np.random.default_rng(3)
+x = (rng.standard_normal((2, 8, 1024, 2048)) + 1j * rng.standard_normal((2, 8, 1024, 2048))).astype(np.complex64)
+xd = [torch.from_numpy(x[i]).cuda() for i in range(2)]
+torch.cuda.synchronize()
+s = [torch.cuda.Stream(), torch.cuda.Stream()]
+out = [None, None]
+for i in range(2):
+    with torch.cuda.stream(s[i]):
+        out[i] = ops.fft2d(xd[i])
+torch.cuda.synchronize()
+for i in range(2):
+    ref = np.fft.fft2(x[i].astype(np.complex128))
+    err = np.linalg.norm(out[i].cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert err <= 1e-5, (i, err)
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110, cwd=root)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_second_device_has_its_own_state(dev):
+    """Host-tier buffers, the twiddle table and the > 64 KiB LDS attribute are per device."""
+    if _lib.lib().mi_device_count() < 2:
+        pytest.skip("one GPU on this box")
+    with torch.cuda.device(1):
+        x = torch.from_numpy(rand_plane(4096, 64, 9)).to("cuda:1")
+        f = ops.fft2d(x)
+        ref = np.fft.fft2(x.cpu().numpy().astype(np.complex128))
+        assert rel_l2(f.cpu().numpy(), ref) <= REL_L2
+        img = np.random.default_rng(1).integers(0, 256, (64, 96, 4), dtype=np.uint8)
+        a, b = np.empty_like(img), np.empty_like(img)
+        ops.imageSobelEdgeWrapper(a, img, 96, 64)
+        ops.imageFFTImageGenerate(b, img, 96, 64)
+    c, e = np.empty_like(img), np.empty_like(img)
+    ops.imageSobelEdgeWrapper(c, img, 96, 64)
+    ops.imageFFTImageGenerate(e, img, 96, 64)
+    assert np.array_equal(a, c) and np.array_equal(b, e)
+

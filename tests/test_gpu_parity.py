@@ -530,3 +530,13 @@ def test_gaussian_sizes_above_15_are_bit_exact(dev, golden, k, sigma):
     ops.filter_strip(_lib.FILTER_GAUSSIAN, d[lo:hi].contiguous(), out, w, h, lo, y0, y1, k, sigma)
     assert np.array_equal(out.cpu().numpy(), want[y0:y1])
 
+
+def test_very_wide_image_leaves_the_32bit_offset_path(dev, golden):
+    """A band of a 12-million-pixel-wide image spans more than 2^31 bytes: the launcher must take the
+    64-bit-address policy instead of wrapping the buffer offsets (or running into their sentinel)."""
+    w, h = 12_000_000, 3
+    img = S.synth_image(5, w, h)
+    d = torch.from_numpy(img).to(dev)
+    assert np.array_equal(ops.sobel(d).cpu().numpy(), golden.sobel(img))
+    assert np.array_equal(ops.mean_blur(d, 3).cpu().numpy(), golden.meanblur(img, 3))
+

@@ -182,6 +182,27 @@ def test_fft2d_4096_roundtrip_parseval_and_256_subcase(dev, golden):
     assert rel_l2(ops.fft2d(sub).cpu().numpy(), ref) <= REL_L2
 
 
+def test_fft2d_4096_batch16_full_spectrum_against_double_precision(dev):
+    """BASELINE.json config 5 at full size: the batch-16 launch of 4096 x 4096 planes, every coefficient
+    of every plane against numpy.fft.fft2 in double precision (numpy.fft itself is pinned to the oracle's
+    DFT in tests/test_oracle.py), forward and back; relative L2 <= 1e-5 per plane."""
+    n, batch = 4096, 16
+    frames = ops.synth(5, n, n, batch=batch)[..., 0].to(torch.float32)     # seed 5, one byte per pixel
+    x = torch.complex(frames, torch.zeros_like(frames))
+    del frames
+    f = ops.fft2d(x)
+    back = ops.fft2d(f, inverse=True)
+    worst_f = worst_b = 0.0
+    for b in range(batch):
+        xb = x[b].real.cpu().numpy().astype(np.float64)
+        ref = np.fft.fft2(xb)
+        worst_f = max(worst_f, rel_l2(f[b].cpu().numpy(), ref))
+        worst_b = max(worst_b, rel_l2(back[b].cpu().numpy() / float(n * n), xb))
+        if b == 0:      # a single-plane launch takes the same kernels: the same bits
+            assert torch.equal(ops.fft2d(x[0].contiguous()), f[0])
+    assert worst_f <= REL_L2 and worst_b <= REL_L2, (worst_f, worst_b)
+
+
 def test_pointwise_stages_match_oracle(dev, golden):
     img = S.synth_image(4, 96, 64)
     planes = ops.u8_to_complex(torch.from_numpy(img).to(dev))

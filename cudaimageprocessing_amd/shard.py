@@ -32,28 +32,32 @@ def _dist():
     return dist
 
 
-def exchange_halo(strip, halo, rank, world, group=None):
-    """Send this strip's first/last `halo` rows to the upper/lower neighbour and receive theirs.
-    Returns (top, bottom, works): top = the rows above the strip (None on rank 0), bottom = the
-    rows below (None on the last rank); wait on every work in `works` before reading them."""
-    import torch
+def _p2p(sends, recvs, group=None):
+    """Neighbour send/recv (no collective).  sends/recvs: lists of (tensor, peer).  Returns a function
+    that waits for the transfers (and finishes the receives) when called.  With the "nccl" backend
+    (RCCL over xGMI) device tensors travel as they are.  "gloo" moves host memory only, so device
+    tensors are staged through host copies -- that is the rehearsal mode for boxes with fewer GPUs than
+    ranks (tests, MI_BENCH_BACKEND=gloo), not the production transport."""
     dist = _dist()
-    ops, top, bottom = [], None, None
-    n = strip.shape[0]
-    if halo > n and world > 1:
-        raise ValueError(f"strip of {n} rows is thinner than the halo ({halo} rows)")
-    if halo == 0 or world == 1:
-        return None, None, []
-    if rank > 0:
-        top = torch.empty((halo,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
-        ops.append(dist.P2POp(dist.isend, strip[:halo].contiguous(), rank - 1, group))
-        ops.append(dist.P2POp(dist.irecv, top, rank - 1, group))
-    if rank < world - 1:
-        bottom = torch.empty((halo,) + tuple(strip.shape[1:]), dtype=strip.dtype, device=strip.device)
-        ops.append(dist.P2POp(dist.isend, strip[n - halo:].contiguous(), rank + 1, group))
-        ops.append(dist.P2POp(dist.irecv, bottom, rank + 1, group))
-    works = dist.batch_isend_irecv(ops) if ops else []
-    return top, bottom, works
+    if not sends and not recvs:
+        return lambda: None
+    staged = dist.get_backend(group) == "gloo" and any(t.is_cuda for t, _ in sends + recvs)
+    if staged:
+        h_send = [(t.cpu(), peer) for t, peer in sends]
+        h_recv = [(t.new_empty(t.shape, device="cpu"), peer) for t, peer in recvs]
+    else:
+        h_send, h_recv = sends, recvs
+    ops = [dist.P2POp(dist.isend, t, peer, group) for t, peer in h_send]
+    ops += [dist.P2POp(dist.irecv, t, peer, group) for t, peer in h_recv]
+    works = dist.batch_isend_irecv(ops)
+
+    def wait():
+        for wk in works:
+            wk.wait()
+        if staged:
+            for (dst, _), (src, _) in zip(recvs, h_recv):
+                dst.copy_(src)
+    return wait
 
 
 def _device_compute(filter_id, ksize, sigma, w, h_total):
@@ -64,46 +68,88 @@ def _device_compute(filter_id, ksize, sigma, w, h_total):
     return compute
 
 
+class StripPlan:
+    """This rank's strip of a w x h_total image with everything a chain of stencil stages needs,
+    allocated once: two buffers of (pad + rows + pad) image rows used in turn as a stage's input and
+    output.  The strip sits in the middle of a buffer; a stage's halo rows are received straight into
+    the `pad` rows around it, so the kernels read strip and halo as one contiguous run of rows -- no
+    per-stage allocation, concatenation or copy.  pad = the deepest halo any stage will ask for."""
+
+    def __init__(self, w, h_total, rank, world, pad, device, group=None):
+        import torch
+        self.w, self.h_total, self.rank, self.world, self.group = w, h_total, rank, world, group
+        self.y0, self.y1 = strip_range(h_total, world, rank)
+        self.n = self.y1 - self.y0
+        self.pad = int(pad)
+        self.bufs = [torch.empty((self.n + 2 * self.pad, w, 4), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.cur = 0
+
+    def strip(self, i=None):
+        """The strip's rows inside buffer i (default: the current one) -- fill this with the input."""
+        b = self.bufs[self.cur if i is None else i]
+        return b[self.pad:self.pad + self.n]
+
+    def run_stage(self, filter_id, ksize=3, sigma=0.0, compute=None):
+        """One filter over the strip: neighbour exchange of `halo` rows, interior rows filtered while
+        the halos travel, then the two edge bands.  Returns the output strip (a view of the other
+        buffer, which becomes the current one)."""
+        halo = _halo_rows(filter_id, ksize)
+        if halo > self.pad:
+            raise ValueError(f"stage needs {halo} halo rows, the plan was made for {self.pad}")
+        src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
+        if compute is None:
+            if not src.is_cuda:
+                raise RuntimeError("strip filtering needs CUDA/HIP tensors (no CPU fallback)")
+            compute = _device_compute(filter_id, ksize, sigma, self.w, self.h_total)
+        n, pad, y0, y1, rank, world = self.n, self.pad, self.y0, self.y1, self.rank, self.world
+        if halo > n and world > 1:
+            raise ValueError(f"strip of {n} rows is thinner than the halo ({halo} rows)")
+        up, down = (rank > 0 and halo > 0), (rank < world - 1 and halo > 0)
+        sends, recvs = [], []
+        if up:
+            sends.append((src[pad:pad + halo], rank - 1))
+            recvs.append((src[pad - halo:pad], rank - 1))
+        if down:
+            sends.append((src[pad + n - halo:pad + n], rank + 1))
+            recvs.append((src[pad + n:pad + n + halo], rank + 1))
+        wait = _p2p(sends, recvs, self.group)
+        a, b = (halo if up else 0), (halo if down else 0)
+        out = dst[pad:pad + n]
+        if n >= 2 * halo and (a or b):
+            if n - a - b > 0:   # interior rows need only local data: filter them while the halos travel
+                compute(src[pad:pad + n], y0, out[a:n - b], y0 + a, y1 - b)
+            wait()
+            if a:     # rows [y0, y0+halo) read input rows [y0-halo, y0+2*halo)
+                compute(src[pad - halo:pad + 2 * halo], y0 - halo, out[:a], y0, y0 + a)
+            if b:     # rows [y1-halo, y1) read input rows [y1-2*halo, y1+halo)
+                compute(src[pad + n - 2 * halo:pad + n + halo], y1 - 2 * halo, out[n - b:], y1 - b, y1)
+        else:         # no neighbours, no halo, or a strip thinner than two halos: one piece
+            wait()
+            compute(src[pad - a:pad + n + b], y0 - a, out, y0, y1)
+        self.cur ^= 1
+        return out
+
+    def run_chain(self, stages, compute_factory=None):
+        """One halo exchange per stage (each stage consumes the halo of the previous stage's output).
+        stages: list of (filter_id, ksize, sigma)."""
+        out = self.strip()
+        for filter_id, ksize, sigma in stages:
+            compute = compute_factory(filter_id, ksize, sigma) if compute_factory else None
+            out = self.run_stage(filter_id, ksize, sigma, compute)
+        return out
+
+
 def strip_filter(strip, filter_id, w, h_total, rank, world, ksize=3, sigma=0.0, group=None, compute=None):
     """Filter this rank's strip (rows strip_range(h_total, world, rank) of the image, shape
-    (rows, w, 4) uint8) and return the same rows of the filtered image.
+    (rows, w, 4) uint8) and return the same rows of the filtered image (convenience form: makes a
+    one-stage StripPlan and copies the strip in; pipelines keep a plan and fill plan.strip()).
 
     `compute(rows_in, in_row0, out, y_begin, y_end)` produces output rows [y_begin, y_end) into
     `out` from input rows starting at global row `in_row0`; the default is the HIP kernel
     (ops.filter_strip).  Tests on CPU pass an oracle-backed function; there is no CPU fallback
     in the product path."""
-    import torch
-    if compute is None:
-        if not strip.is_cuda:
-            raise RuntimeError("strip_filter needs CUDA/HIP tensors (no CPU fallback)")
-        compute = _device_compute(filter_id, ksize, sigma, w, h_total)
-    halo = _halo_rows(filter_id, ksize)
-    y0, y1 = strip_range(h_total, world, rank)
-    n = y1 - y0
-    assert strip.shape[0] == n and strip.shape[1] == w, "strip does not match strip_range()"
-    out = torch.empty_like(strip)
-    top, bottom, works = exchange_halo(strip, halo, rank, world, group)
-
-    a = halo if top is not None else 0
-    b = halo if bottom is not None else 0
-    if n >= 2 * halo and (a or b):
-        # interior rows need only local data: filter them while the halos travel
-        if n - a - b > 0:
-            compute(strip, y0, out[a:n - b], y0 + a, y1 - b)
-        for wk in works:
-            wk.wait()
-        if a:     # rows [y0, y0+halo) read input rows [y0-halo, y0+2*halo)
-            compute(torch.cat([top, strip[:2 * halo]]), y0 - halo, out[:a], y0, y0 + a)
-        if b:     # rows [y1-halo, y1) read input rows [y1-2*halo, y1+halo)
-            compute(torch.cat([strip[n - 2 * halo:], bottom]), y1 - 2 * halo, out[n - b:], y1 - b, y1)
-    else:
-        # no neighbours, no halo, or a strip thinner than two halos: one piece
-        for wk in works:
-            wk.wait()
-        parts = [t for t in (top, strip, bottom) if t is not None]
-        rows_in = torch.cat(parts) if len(parts) > 1 else strip
-        compute(rows_in, y0 - a, out, y0, y1)
-    return out
+    return strip_chain(strip, [(filter_id, ksize, sigma)], w, h_total, rank, world, group,
+                       (lambda f, k, s: compute) if compute else None)
 
 
 def _halo_rows(filter_id, ksize):
@@ -118,10 +164,13 @@ def _halo_rows(filter_id, ksize):
 
 
 def strip_chain(strip, stages, w, h_total, rank, world, group=None, compute_factory=None):
-    """A chain of filters on strips, one halo exchange per stage (each stage consumes the halo
-    of the previous stage's output).  stages: list of (filter_id, ksize, sigma)."""
-    cur = strip
-    for filter_id, ksize, sigma in stages:
-        compute = compute_factory(filter_id, ksize, sigma) if compute_factory else None
-        cur = strip_filter(cur, filter_id, w, h_total, rank, world, ksize, sigma, group, compute)
-    return cur
+    """A chain of filters on strips, one halo exchange per stage.  stages: list of
+    (filter_id, ksize, sigma).  Convenience form of StripPlan.run_chain."""
+    if compute_factory is None and not strip.is_cuda:
+        raise RuntimeError("strip filtering needs CUDA/HIP tensors (no CPU fallback)")
+    y0, y1 = strip_range(h_total, world, rank)
+    assert strip.shape[0] == y1 - y0 and strip.shape[1] == w, "strip does not match strip_range()"
+    pad = max([_halo_rows(f, k) for f, k, _ in stages] + [0])
+    plan = StripPlan(w, h_total, rank, world, pad, strip.device, group)
+    plan.strip().copy_(strip)
+    return plan.run_chain(stages, compute_factory)

@@ -2,7 +2,7 @@
 """bench.py -- BASELINE.json's headline metric: megapixels/s of the filter chain
 (gray -> Gaussian 5x5 -> median 3x3 -> Sobel) on 3840x2160 RGBA u8 frames, device-resident.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--unfused]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--unfused] [--legs c3,c4,c5]
 
 A step is one pass of the chain over one batch of B synthetic frames per GPU (inputs already in
 HBM): one launch of the fused chain kernel (mi_chain_gray_gauss5_median3_sobel_u8x4_dev, output
@@ -15,9 +15,16 @@ Extra objects in the line:
   roofline      the kernel of the timed step (the slowest of the four with --unfused):
                 algorithmic bytes (8 B/pixel: 4 read + 4 written) per launch / its
                 average launch duration, measured with HIP events on the launch stream inside
-                the timed region, against 8 TB/s.
+                the timed region, against 8 TB/s.  `traffic` is NOT measured by this run: it is
+                the rocprofv3 --pmc figure for the same kernel and workload kept in profiles/
+                (`traffic_source` names the file and its date).
   unfused       the same chain as four kernels (32 B/pixel through HBM), timed right after the
-                K steps with the same events: per-filter ms, MP/s, GB/s and roofline fraction.
+                K steps with the same events and the same spin-up: per-filter ms, MP/s, GB/s.
+  c3, c4, c5    BASELINE.json's other configurations at this N (--legs, default all; each has its own
+                `roofline`): c3 = 4096 1920x1080 frames batch-sharded over the N GPUs (strong scaling);
+                c4 = one 32768x32768 image in N row strips, Gaussian 15x15 and median 5x5, with the
+                RCCL neighbour halo exchange inside the timed region; c5 = 2-D FFT + inverse FFT of
+                16 4096x4096 planes per GPU (weak scaling).
   cpu_baseline  the CPU oracle (a scalar C port of the reference's arithmetic) timed on this
                 host on a bounded sample of the same workload, rank 0 at N=1 only.
 """
@@ -34,6 +41,7 @@ if ROOT not in sys.path:
 W, H = 3840, 2160
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 BYTES_PER_PIXEL = 8.0           # algorithmic: 4 read + 4 written per u8x4 -> u8x4 filter
+FFT_BYTES_PER_PIXEL = 64.0      # forward + inverse 2-D C2C fp32: 2 directions x 2 line passes x (8 R + 8 W)
 STAGES = ["grayscale", "gaussian5", "median3", "sobel"]
 KERNELS = {"grayscale": "gray_kernel", "gaussian5": "gauss_sep_kernel<2>", "median3": "median3_kernel",
            "sobel": "sobel_kernel", "fused": "chain_kernel"}
@@ -54,6 +62,148 @@ def cpu_baseline(frames=1, threads=1):
     return frames * W * H / 1e6 / dt, dt
 
 
+class Timer:
+    """Wall time of `steps` calls of fn between two barriers, MAX over ranks; also the mean duration of
+    each call from events on the launch stream inside the timed region."""
+
+    def __init__(self, torch, dist, dev, backend):
+        self.torch, self.dist, self.dev, self.backend = torch, dist, dev, backend
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run(self, fn, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        stream = torch.cuda.current_stream()
+        self.barrier()
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(stream)
+            fn()
+            b.record(stream)
+        self.barrier()
+        elapsed = self.max_over_ranks(time.perf_counter() - t0)
+        call_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        return elapsed, call_ms
+
+
+def roofline(kernel, alg_bytes, ms, traffic=None, **extra):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms}
+    r.update(extra)
+    return r
+
+
+def leg_c3(torch, ops, timer, rank, world, dev, steps):
+    """C3: 4096 synthetic 1920x1080 frames, contiguous ceil(4096/N) frames per GPU, no communication."""
+    from cudaimageprocessing_amd import shard
+    w, h, total = 1920, 1080, 4096
+    f0, f1 = shard.batch_range(total, world, rank)
+    n = f1 - f0
+    frames = ops.synth(1000, w, h, batch=n, first_idx=f0 * w * h, device=dev)   # frame f = pixels [f*w*h, (f+1)*w*h) of stream 1000
+    a, b = torch.empty_like(frames), torch.empty_like(frames)
+    elapsed, ms = timer.run(lambda: ops.fused_chain(frames, 1.0, a), steps, 2)
+
+    def four():
+        ops.grayscale(frames, a)
+        ops.gaussian_blur(a, 5, 1.0, b)
+        ops.median_blur(b, 3, a)
+        ops.sobel(a, b)
+    elapsed4, ms4 = timer.run(four, steps, 1)
+    px = n * w * h
+    return {"workload": f"{total} frames {w}x{h} RGBA u8, frames [{f0},{f1}) on rank 0, fused chain, one launch per step",
+            "scaling": "strong", "frames_per_gpu": n, "steps": steps,
+            "value": total * w * h / 1e6 * steps / elapsed, "unit": "MP/s", "ms_per_step": elapsed / steps * 1e3,
+            "roofline": roofline("chain_kernel", px * BYTES_PER_PIXEL, ms),
+            "unfused": {"value": total * w * h / 1e6 * steps / elapsed4, "unit": "MP/s", "ms_per_step": elapsed4 / steps * 1e3,
+                        "GB/s_rank0": px * 4 * BYTES_PER_PIXEL / (ms4 * 1e-3) / 1e9}}
+
+
+def leg_c4(torch, ops, timer, rank, world, dev, steps):
+    """C4: one 32768x32768 image in N row strips; Gaussian 15x15 (sigma 2.5) and median 5x5, each a stage
+    of shard.StripPlan: neighbour halo exchange (RCCL send/recv), interior rows meanwhile, edge bands."""
+    from cudaimageprocessing_amd import _lib, shard
+    w = h = 32768
+    filters = {"gaussian15": (_lib.FILTER_GAUSSIAN, 15, 2.5, "gauss_sep_kernel<7>"),
+               "median5": (_lib.FILTER_MEDIAN, 5, 0.0, "median5_kernel")}
+    pad = max(shard._halo_rows(f, k) for f, k, _, _ in filters.values())
+    plan = shard.StripPlan(w, h, rank, world, pad, dev)
+    strip = plan.strip(0)
+    ops_chunk = 1 << 28       # pixels per generator launch
+    flat = strip.view(-1, 4)
+    for p0 in range(0, plan.n * w, ops_chunk):
+        cnt = min(ops_chunk, plan.n * w - p0)
+        _lib.check(_lib.lib().mi_synth_u8x4_dev(flat[p0:].data_ptr(), 4, plan.y0 * w + p0, cnt, None))
+    torch.cuda.synchronize()
+    out = {"workload": f"{w}x{h} RGBA u8 in {world} row strip(s) of {plan.n} rows, halo exchange inside the timed region",
+           "scaling": "strong", "steps": steps, "halo_rows": pad, "halo_bytes_per_direction": pad * w * 4, "per_filter": {}}
+    for name, (fid, k, sigma, kernel) in filters.items():
+        def stage():
+            plan.cur = 0                      # the input stays in buffer 0; a stage writes buffer 1
+            plan.run_stage(fid, k, sigma)
+        elapsed, ms = timer.run(stage, steps, 1)
+        halo = shard._halo_rows(fid, k)
+        # the same rows as ONE launch with the halos already in place (no exchange): the compute alone
+        a = halo if rank > 0 else 0
+        b = halo if rank < world - 1 else 0
+        src, dst = plan.bufs[0], plan.bufs[1]
+
+        def compute_only():
+            ops.filter_strip(fid, src[pad - a:pad + plan.n + b], dst[pad:pad + plan.n], w, h, plan.y0 - a, plan.y0, plan.y1, k, sigma)
+        _, ms_compute = timer.run(compute_only, steps, 1)
+
+        def exchange_only():
+            sends, recvs = [], []
+            if a:
+                sends.append((src[pad:pad + halo], rank - 1)); recvs.append((src[pad - halo:pad], rank - 1))
+            if b:
+                sends.append((src[pad + plan.n - halo:pad + plan.n], rank + 1)); recvs.append((src[pad + plan.n:pad + plan.n + halo], rank + 1))
+            shard._p2p(sends, recvs)()
+        ms_halo = 0.0
+        if world > 1:
+            _, ms_halo = timer.run(exchange_only, steps, 1)
+        out["per_filter"][name] = {
+            "value": w * h / 1e6 * steps / elapsed, "unit": "MP/s", "ms_per_step": elapsed / steps * 1e3,
+            "stage_ms_rank0": ms, "compute_only_ms_rank0": ms_compute, "halo_exchange_only_ms_rank0": ms_halo,
+            "roofline": roofline(kernel, plan.n * w * BYTES_PER_PIXEL, ms_compute,
+                                 note="this rank's strip as one launch; stage_ms adds the exchange and the edge-band launches")}
+    return out
+
+
+def leg_c5(torch, ops, timer, rank, world, dev, steps):
+    """C5: 2-D fp32 FFT + inverse FFT of 16 4096x4096 planes per GPU (batch-sharded: replicas only)."""
+    n, batch = 4096, 16
+    gray = ops.synth(5, n, n, batch=batch, first_idx=rank * batch * n * n, device=dev)[..., 0].to(torch.float32)
+    x = torch.complex(gray, torch.zeros_like(gray))
+    del gray
+    f, y = torch.empty_like(x), torch.empty_like(x)
+
+    def roundtrip():
+        ops.fft2d(x, out=f)
+        ops.fft2d(f, inverse=True, out=y)
+    elapsed, ms = timer.run(roundtrip, steps, 2)
+    px = batch * n * n
+    return {"workload": f"fft2d + inverse fft2d, {batch} planes {n}x{n} complex fp32 per GPU, out of place",
+            "scaling": "weak", "steps": steps, "value": world * px / 1e6 * steps / elapsed, "unit": "MP/s",
+            "ms_per_step": elapsed / steps * 1e3, "dtype": "f32",
+            "roofline": roofline("fft_lines_kernel (3 line passes per direction)", px * FFT_BYTES_PER_PIXEL, ms,
+                                 note="64 B/px algorithmic: 2 directions x 2 line passes x (8 B read + 8 B written)")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +212,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="3840x2160 frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the four single-filter kernels as the step")
+    ap.add_argument("--legs", default="c3,c4,c5", help="extra configurations to run after the headline one ('' = none)")
+    ap.add_argument("--leg-steps", type=int, default=10)
     args = ap.parse_args()
 
     import torch
@@ -86,17 +238,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    timer = Timer(torch, dist, dev, backend)
 
     B = args.batch
     # frames [rank*B, (rank+1)*B) of the synthetic stream with seed 2
     frames = ops.synth(2, W, H, batch=B, first_idx=rank * B * W * H, device=dev)
     bufs = [torch.empty_like(frames) for _ in range(4)]
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def unfused_step(events=None):
         stream = torch.cuda.current_stream()
@@ -126,36 +273,40 @@ def main():
     step = unfused_step if args.unfused else fused_step
     n_ev = 5 if args.unfused else 2
 
-    # Set-up, before the W warm-up steps: keep the device busy for ~0.1 s so that its clocks are
-    # up.  A launch lasts 0.25 ms; the first ~50 ms of work after idle run about 20 % slower
-    # (measured: 433 GP/s over steps 4..23, 533 GP/s in steady state), which would make a short
-    # run a measurement of the power-state ramp rather than of the kernel.
-    for _ in range(400):
-        step()
-    torch.cuda.synchronize()
+    def spin_up(fn, seconds=0.1):
+        # Set-up, before the W warm-up steps: keep the device busy for ~0.1 s so that its clocks are
+        # up.  A launch lasts 0.25 ms; the first ~50 ms of work after idle run about 20 % slower
+        # (measured: 433 GP/s over steps 4..23, 533 GP/s in steady state), which would make a short
+        # run a measurement of the power-state ramp rather than of the kernel.
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+
+    spin_up(step)
     for _ in range(args.warmup):
         step()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
-    barrier()
+    timer.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    timer.barrier()
+    elapsed = timer.max_over_ranks(time.perf_counter() - t0)
 
     # per-kernel launch durations (ms) from the events recorded inside the timed region
     per_kernel = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
                   for i in range(n_ev - 1)]
 
-    # the four-kernel chain, timed after the K steps (same buffers, same events)
+    # the four-kernel chain, timed after the K steps (same buffers, same events, same spin-up: the
+    # kernels differ from the timed ones, so their first launches would otherwise be cold)
     if args.unfused:
         per_stage, unfused_elapsed = per_kernel, elapsed
     else:
-        unfused_step()
+        spin_up(unfused_step)
+        for _ in range(max(5, args.warmup // 4)):
+            unfused_step()
         ev4 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -166,13 +317,31 @@ def main():
         per_stage = [sum(ev4[k][i].elapsed_time(ev4[k][i + 1]) for k in range(args.steps)) / args.steps
                      for i in range(4)]
 
+    legs = {}
+    del bufs[:3]
+    for leg in [s for s in args.legs.split(",") if s]:
+        fn = {"c3": leg_c3, "c4": leg_c4, "c5": leg_c5}.get(leg)
+        if fn is None:
+            raise SystemExit(f"unknown leg {leg!r} (known: c3, c4, c5)")
+        torch.cuda.empty_cache()
+        try:
+            legs[leg] = fn(torch, ops, timer, rank, world, dev, args.leg_steps)
+        except torch.OutOfMemoryError as e:          # a smaller or shared GPU: say so, keep the headline
+            legs[leg] = {"skipped": f"out of device memory: {str(e)[:120]}"}
+            if dist is not None:
+                raise                                 # ranks must not diverge
+        torch.cuda.empty_cache()
+
     if rank == 0:
         px_per_launch = B * W * H
         mp_total = world * B * W * H / 1e6 * args.steps
         alg_bytes = px_per_launch * BYTES_PER_PIXEL
-        traffic = {}
+        traffic, traffic_source = {}, None
         if os.path.exists(TRAFFIC_FILE) and B == 16:
             traffic = json.load(open(TRAFFIC_FILE))
+            traffic_source = ("not measured in this run: profiles/traffic_bytes_per_launch.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                              "WRITE_SIZE per launch, same workload), file dated "
+                              + time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(TRAFFIC_FILE))))
 
         def gbs(ms):
             return alg_bytes / (ms * 1e-3) / 1e9
@@ -205,13 +374,11 @@ def main():
             "config": {"workload": f"C2 chain gray->gauss5(sigma 1.0)->median3->sobel, {W}x{H} RGBA u8, "
                                    f"batch {B} frames per GPU, device-resident, {desc}",
                        "frames_per_gpu": B, "width": W, "height": H, "sharding": f"batch x{world}"},
-            "roofline": {"kernel": kname, "bound": "hbm", "achieved": gbs(kms),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(kms) / HBM_PEAK_GBS,
-                         "traffic": traffic.get(kname),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": kms},
+            "roofline": roofline(kname, alg_bytes, kms, traffic.get(kname), traffic_source=traffic_source),
             "unfused": {"value": B * W * H / 1e6 * args.steps / unfused_elapsed, "unit": "MP/s (rank 0)",
                         "ms_per_step": unfused_elapsed / args.steps * 1e3, "per_filter": per_filter},
         }
+        out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             v, dt = cpu_baseline(frames=8, threads=1)
             out["cpu_baseline"] = {"value": v, "unit": "MP/s", "cores": 1, "kind": "port",

@@ -18,6 +18,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
+# MI_EXTRA_CXXFLAGS: extra compiler flags for experiment builds (tools/make_variant.sh), e.g. -DMI_CHAIN_DBG=1
+import shlex  # noqa: E402
+FLAGS += shlex.split(os.environ.get("MI_EXTRA_CXXFLAGS", ""))
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True

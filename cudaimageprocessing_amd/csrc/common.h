@@ -214,6 +214,7 @@ struct RowIO<0> {
         return lane == 0 ? h.w : h.x;
     }
     MI_DEV void store(int y, u32x4 v) const { if (productive) store_px4<0>(out, *g, y, cx, v); }
+    MI_DEV void store_in_band(int y, u32x4 v) const { store(y, v); }
 };
 
 template <>
@@ -288,6 +289,13 @@ struct RowIO<1> {
     MI_DEV void store(int y, u32x4 v) const
     {   // aux 2 = nt: streaming store, the output is not read again by this kernel
         __builtin_amdgcn_raw_buffer_store_b128(v, rout, (u32)((y - ylo) * pitch) + out_off, 0, 2);
+    }
+    // The same with the row's offset in the instruction's scalar offset (no vector add per row).  The
+    // hardware leaves the scalar offset out of its range check: only for rows INSIDE the band (a lane
+    // that must not store is still dropped through its out-of-range out_off).
+    MI_DEV void store_in_band(int y, u32x4 v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, out_off, (y - ylo) * pitch, 2);
     }
 };
 

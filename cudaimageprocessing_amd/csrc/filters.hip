@@ -163,8 +163,10 @@ MI_DEV u32 sobel_mag_h(u32 gxgy)
     const h16x2 v = __builtin_bit_cast(h16x2, gxgy);
     const float d = __builtin_amdgcn_fdot2(v, v, 0.5f, false);
     const float f = __builtin_amdgcn_sqrtf(d);
-    u32 m = (u32)f;
-    return m > 255u ? 255u : m;
+    // floor(f), saturated at 255, in one conversion: v_cvt_pk_u8_f32 rounds to nearest and saturates, and
+    // f - 0.5 is never within 0.001 of a tie (f = sqrt(s + 0.5) stays that far from every integer for
+    // s < 256^2; beyond, it saturates) -- one slot where v_cvt_u32_f32 + v_min_u32 take three
+    return __builtin_amdgcn_cvt_pk_u8_f32(f - 0.5f, 0u, 0u);
 }
 
 MI_DEV u32 pk_f16(float lo, float hi) { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(lo, hi)); }
@@ -710,11 +712,25 @@ __global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __re
 // it, so the result is bit-identical to running the four kernels one after the other.
 // The stages have a combined reach of 4 pixels: strips overlap by MRG >= 1 lanes on each side
 // (64 - 2 MRG productive lanes) and a band reads 4 extra rows above and below.
+// MI_CHAIN_DBG (experiment builds only, tools/make_variant.sh with MI_EXTRA_CXXFLAGS=-DMI_CHAIN_DBG=n): what a
+// stage costs, measured by leaving it out -- 1: loads and stores only, 2: no square root, 3: no median,
+// 4: no grayscale arithmetic, 5: no Gaussian, 6: arithmetic only (no loads in the loop, no stores).  The results are wrong by construction; 0 is the product.
+#ifndef MI_CHAIN_DBG
+#define MI_CHAIN_DBG 0
+#endif
+#ifndef MI_CHAIN_BURST
+#define MI_CHAIN_BURST 3  // rows per request burst (ring of 2 * BURST rows per wave in LDS); 0: one row per step, in registers
+#endif
+#ifndef MI_CHAIN_WAVES
+#define MI_CHAIN_WAVES 1  // waves per SIMD the register allocation must allow (1: whatever the code needs)
+#endif
 template <int POL, int MRG>
-__global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
+__global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g,
                                                     const GaussW gw)
 {
+    // per wave: a ring of 2 * MI_CHAIN_BURST input rows of 1 KiB (see `run` below)
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[(POL == 1 && MI_CHAIN_BURST > 0) ? 4 * 2 * MI_CHAIN_BURST * 1024 : 16];
     const WaveJob j = wave_job(g);
     if (!j.valid) return;
     constexpr int OUTW = 4 * (64 - 2 * MRG);
@@ -738,7 +754,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
             const f32x2 bl = {(float)((a >> 16) & 0xffu), (float)((b >> 16) & 0xffu)};
             const f32x2 t = 0.587f * gg;
             const f32x2 u = __builtin_elementwise_fma((f32x2)(0.299f), r, t);
-            const f32x2 v = __builtin_elementwise_fma((f32x2)(0.114f), bl, u);
+            f32x2 v = __builtin_elementwise_fma((f32x2)(0.114f), bl, u);
+            if constexpr (MI_CHAIN_DBG == 4) v = r;
             f[2 + 2 * q] = __builtin_floorf(v.x);        // == (float)(uchar)v, v >= 0
             f[3 + 2 * q] = __builtin_floorf(v.y);
         }
@@ -752,6 +769,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
 #pragma unroll
             for (int t = 1; t < 5; t++)
                 sum = __builtin_elementwise_fma((f32x2)(gw.w[t]), f32x2{f[2 * q + t], f[2 * q + 1 + t]}, sum);
+            if constexpr (MI_CHAIN_DBG == 5) sum = f32x2{f[2 * q + 2], f[2 * q + 3]};
             h[q] = sum;
         }
     };
@@ -769,9 +787,43 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
     // packed f16 pairs (see sobel_mag_h), in rings indexed by step mod 5 like `win`: with the loop unrolled by 5
     // every index is a compile-time constant and no row is ever copied
     u32 G01[5] = {0, 0, 0, 0, 0}, G23[5] = {0, 0, 0, 0, 0}, M01[5] = {0, 0, 0, 0, 0}, M23[5] = {0, 0, 0, 0, 0};
+    // How the input rows arrive.  With its arithmetic removed this kernel took the same time as with it:
+    // it was bound by the shape of its memory accesses -- one row per step requested by each of thousands of
+    // bands.  As a pure copy that shape runs at 4.9 TB/s; requesting K consecutive rows of the strip at one
+    // time runs at 5.4 (tools/marchbench.hip, profiles/r02_marchbench.txt).  So (aligned images) the wave
+    // requests its rows in BURSTS of K = MI_CHAIN_BURST, every K steps, for the NEXT K steps, straight into
+    // a ring of 2K rows in LDS (buffer_load ... lds: no registers are held by rows in flight, the occupancy
+    // stays at six waves per SIMD) and reads one row back per step.  hipcc does not order a ds_read behind
+    // an LDS-DMA write, so the wait is explicit: vector-memory operations complete in order, and after a
+    // burst is issued the only younger ones than the previous burst are the K stores of the steps in
+    // between and the K loads just issued -- s_waitcnt vmcnt(2K) (vmcnt(K) for the first bursts of a band,
+    // which have fewer stores before them) means "the rows of the next K steps have landed".
+    constexpr bool LDSQ = POL == 1 && MI_CHAIN_BURST > 0;
+    constexpr int K = MI_CHAIN_BURST > 0 ? MI_CHAIN_BURST : 1;
+    [[maybe_unused]] unsigned char* myring = nullptr;
+    u32x4 nxt = {0u, 0u, 0u, 0u};
+    auto dma_row = [&](int row, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass only needs the kernel's stub)
+        if constexpr (POL == 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(myring + slot * 1024), 16,
+                                                     (row - io.row0) * io.pitch + io.in_off, 0, 0, 0);
+#endif
+    };
+    auto wait_vm = [](auto n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n)::value) : "memory");
+#endif
+    };
 #pragma unroll
     for (int i = 0; i < 4; i++) gray_hrow(io.load(mch.row(i - 4)), win[i]);
-    u32x4 nxt = io.load(mch.row(0));
+    if constexpr (LDSQ) {
+        myring = ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * K * 1024);
+#pragma unroll
+        for (int p = 0; p < K; p++) dma_row(mch.row(p), p);
+    } else {
+        nxt = io.load(mch.row(0));
+    }
+    int phase = 0, slot = 0;     // step i: phase = i % K, slot = i % 2K (wave-uniform)
 
     const int steps = mch.n + 4;   // input steps 0 .. n+3; step i completes output row i-4
     for (int base = 0; base < steps; base += 5) {
@@ -779,8 +831,29 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
         for (int s = 0; s < 5; s++) {
             const int i = base + s;
             if (i < steps) {
-            gray_hrow(nxt, win[(4 + s) % 5]);
-            nxt = io.load(mch.row(i + 1));
+            u32x4 cur;
+            if constexpr (LDSQ) {
+                if (phase == 0) {
+                    const int first = slot >= K ? 0 : K;          // the half of the ring the last K steps have read
+#pragma unroll
+                    for (int p = 0; p < K; p++) dma_row(mch.row(i + K + p), first + p);
+                    // (steps 0..3 store nothing: until step 4 + K the count of stores in between is below K;
+                    // waiting for more than necessary is always safe)
+                    if (i < 4 + K) wait_vm(std::integral_constant<int, K>{});
+                    else wait_vm(std::integral_constant<int, 2 * K>{});
+                }
+                cur = *reinterpret_cast<const u32x4*>(myring + slot * 1024 + 16 * j.lane);
+                phase = phase + 1 == K ? 0 : phase + 1;
+                slot = slot + 1 == 2 * K ? 0 : slot + 1;
+            } else {
+                cur = nxt;
+                if (MI_CHAIN_DBG != 6 || g.batch < 0) nxt = io.load(mch.row(i + 1));
+            }
+            if constexpr (MI_CHAIN_DBG == 1) {
+                if (i >= 4) io.store(mch.row(i - 4), cur);
+                continue;
+            }
+            gray_hrow(cur, win[(4 + s) % 5]);
             // ---- Gaussian column pass: row(i-2), zero outside the write set
             const u32 grow = rowmask(mch.row(i - 2));
             float fb[4];
@@ -789,6 +862,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 f32x2 a = gw.w[2] * win[(s + 2) % 5][q];
                 a = __builtin_elementwise_fma((f32x2)(gw.w[0]), win[s % 5][q] + win[(s + 4) % 5][q], a);
                 a = __builtin_elementwise_fma((f32x2)(gw.w[1]), win[(s + 1) % 5][q] + win[(s + 3) % 5][q], a);
+                if constexpr (MI_CHAIN_DBG == 5) a = win[(s + 2) % 5][q];
                 fb[2 * q] = __builtin_truncf(a.x);
                 fb[2 * q + 1] = __builtin_truncf(a.y);
             }
@@ -800,8 +874,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
             u32 l23 = G23[(s + 3) % 5], m23 = G23[(s + 4) % 5], h23 = gb23;
             sort2(l01, m01); sort2(m01, h01); sort2(l01, m01);
             sort2(l23, m23); sort2(m23, h23); sort2(l23, m23);
-            u32 med01, med23;
-            {
+            // (a band's first steps only prime the rings: the median's first needed row is step 2's, Sobel's
+            // first row step 4's -- the stages are skipped until then, 5 % of a 30-row band's arithmetic)
+            u32 med01 = 0u, med23 = 0u;
+            if constexpr (MI_CHAIN_DBG == 3) { med01 = G01[(s + 4) % 5]; med23 = G23[(s + 4) % 5]; } else
+            if (i >= 2) {
                 const u32 lL = from_left(l23), mL = from_left(m23), hL = from_left(h23);
                 const u32 lR = from_right(l01), mR = from_right(m01), hR = from_right(h01);
                 const u32 la = __builtin_amdgcn_alignbit(l01, lL, 16), lb = __builtin_amdgcn_alignbit(l23, l01, 16), lc = __builtin_amdgcn_alignbit(lR, l23, 16);
@@ -814,7 +891,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
             }
             M01[s] = med01; M23[s] = med23;
             // ---- Sobel: row(i-4) from the median rows of steps i-2, i-1, i
-            {
+            if (i >= 4) {
                 const u32 mt01 = M01[(s + 3) % 5], mt23 = M23[(s + 3) % 5], mm01 = M01[(s + 4) % 5], mm23 = M23[(s + 4) % 5];
                 const u32 V01 = h_fma2(mm01, h_add(mt01, med01)), V23 = h_fma2(mm23, h_add(mt23, med23));
                 const u32 D01 = h_sub(med01, mt01), D23 = h_sub(med23, mt23);
@@ -835,13 +912,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const u32* __restrict__ in,
                 u32 o[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
+                    if constexpr (MI_CHAIN_DBG == 2) o[k] = gray_opaque(P[k] & 0xffu); else
                     o[k] = gray_opaque(sobel_mag_h(P[k]));
                     if constexpr (EDGE) o[k] &= xm[k] & srow;
                 }
-                // the first four steps complete rows of the neighbouring band: the buffer form drops
-                // them by itself (its descriptor spans this band's rows only), and with no branch
-                // here the next row's load stays at the top of the step
-                if (POL == 1 || i >= 4) io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+                if (MI_CHAIN_DBG != 6 || g.batch < 0) io.store_in_band(y, u32x4{o[0], o[1], o[2], o[3]});
             }
             }
         }
@@ -1334,11 +1409,12 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     if (mrg != 1 && mrg != 2) mrg = (W + 239) / 240 <= (W + 247) / 248 ? 2 : 1;
     const int outw = 4 * (64 - 2 * mrg);
     g.strips = (W + outw - 1) / outw;
-    // tall bands amortise the 8 extra rows a band runs through the early stages (measured flat
-    // between 24 and 36 rows, slower beyond); shrink them only to fill the machine
+    // tall bands amortise the 8 extra rows a band runs through the early stages, short ones keep the
+    // rows that are requested at one time close together (measured: best at 32..34 rows, 2 % slower at
+    // 30 and 36, 4 % at 42); shrink them only to fill the machine
     int rpb = tuning().chain_rows_per_band;
     if (rpb <= 0) {
-        rpb = 30;
+        rpb = 34;
         // (small batches: measured on 1, 2 and 4 4K frames and on single 1080p and 675x900 frames)
         while (rpb > 8 && (i64)batch * g.strips * ((H + rpb - 1) / rpb) < 4096) rpb >>= 1;
     }

@@ -299,3 +299,104 @@ struct RowIO<1> {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// RowFeed: the input rows of a marching wave, requested in BURSTS.
+//
+// A wave that asks for one row per step presents the memory system with thousands of slow, widely
+// spaced row streams; asking for K consecutive rows of the strip at one time runs 3..10 % faster as
+// a pure copy (tools/marchbench.hip, profiles/r02_marchbench.txt).  For aligned images (POL 1) the
+// rows go straight into a per-wave ring of 2K rows in LDS (buffer_load ... lds: rows in flight hold
+// no registers, so occupancy is unchanged) and come back one per step with a ds_read; every K steps
+// the wave requests the rows of the NEXT K steps.  hipcc does not order a ds_read behind an LDS-DMA
+// write, so the wait is explicit.  Vector-memory operations complete in order: after a burst of L
+// loads is issued, the only operations younger than the PREVIOUS burst are the stores of the K
+// steps in between (one per step once the kernel has primed, none before) and the L loads just
+// issued, so s_waitcnt vmcnt(K + L) -- vmcnt(L) while fewer than K stores can lie in between --
+// means "the rows of the next K steps have landed".  Waiting for more than necessary is always safe.
+//
+// HALO1: each row also carries the one pixel next to the strip on either side (3x3 filters), a dword
+// per edge lane in a second, 256-byte part of the ring slot.
+// Usage: feed.start(first_row_index) once, then feed.next(c, prime) for consumption c = 0, 1, 2, ...
+// (rows first, first+1, ... in marching order); `prime` = consumptions before the kernel's first store.
+// For POL 0 the feed degenerates to the one-row-ahead register prefetch.
+template <int POL, int K_, bool HALO1>
+struct RowFeed {
+    static constexpr bool LDSQ = POL == 1 && K_ > 0;   // K_ = 0: the register prefetch for every policy
+    static constexpr int K = K_ > 0 ? K_ : 1;
+    static constexpr int SLOT_BYTES = HALO1 ? 1280 : 1024;
+    static constexpr int WAVE_BYTES = 2 * K * SLOT_BYTES;
+    static constexpr int BLOCK_BYTES = LDSQ ? 4 * WAVE_BYTES : 16;    // the __shared__ ring a 256-lane block declares
+    static constexpr int L = HALO1 ? 2 * K : K;           // loads per burst
+    struct Row { u32x4 p; u32 h; };
+
+    const RowIO<POL>& io;
+    const March& mch;
+    unsigned char* ring;       // this wave's 2K slots
+    int first, lane;
+    int phase = 0, slot = 0;
+    Row nxt{};                 // POL 0 only
+
+    MI_DEV RowFeed(const RowIO<POL>& io_, const March& m_, unsigned char* block_ring, int lane_)
+        : io(io_), mch(m_), ring(block_ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * WAVE_BYTES), first(0), lane(lane_) {}
+
+    MI_DEV void request(int row, int s)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (LDSQ) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(ring + s * SLOT_BYTES), 16,
+                                                     (row - io.row0) * io.pitch + io.in_off, 0, 0, 0);
+            if constexpr (HALO1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(ring + s * SLOT_BYTES + 1024), 4,
+                                                         (row - io.row0) * io.pitch + io.halo1_off, 0, 0, 0);
+        }
+#endif
+    }
+    template <int N>
+    static MI_DEV void wait_vm()
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+    }
+    MI_DEV Row load_direct(int row) const
+    {
+        Row r;
+        r.p = io.load(row);
+        r.h = HALO1 ? io.load_halo1(row) : 0u;
+        return r;
+    }
+    // requests rows first .. first+K-1 (marching order)
+    MI_DEV void start(int first_index)
+    {
+        first = first_index;
+        if constexpr (LDSQ) {
+#pragma unroll
+            for (int p = 0; p < K; p++) request(mch.row(first + p), p);
+        } else {
+            nxt = load_direct(mch.row(first));
+        }
+    }
+    // the row of consumption c (= row index first + c); c must count 0, 1, 2, ...
+    MI_DEV Row next(int c, int prime)
+    {
+        Row r;
+        if constexpr (LDSQ) {
+            if (phase == 0) {
+                const int half = slot >= K ? 0 : K;      // the half of the ring the last K consumptions have read
+#pragma unroll
+                for (int p = 0; p < K; p++) request(mch.row(first + c + K + p), half + p);
+                if (c < prime + K) wait_vm<L>(); else wait_vm<K + L>();
+            }
+            const unsigned char* sl = ring + slot * SLOT_BYTES;
+            r.p = *reinterpret_cast<const u32x4*>(sl + 16 * lane);
+            r.h = HALO1 ? *reinterpret_cast<const u32*>(sl + 1024 + 4 * lane) : 0u;
+            phase = phase + 1 == K ? 0 : phase + 1;
+            slot = slot + 1 == 2 * K ? 0 : slot + 1;
+        } else {
+            r = nxt;
+            nxt = load_direct(mch.row(first + c + 1));
+        }
+        return r;
+    }
+};
+

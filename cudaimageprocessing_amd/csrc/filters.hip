@@ -89,6 +89,11 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
     r23 = __builtin_amdgcn_perm(p.w, p.z, 0x0c040c00u);
 }
 
+#ifndef MI_FEED_K
+#define MI_FEED_K 0       // rows per request burst of the 3x3 march kernels (RowFeed in common.h); 0: one row ahead, in registers
+                          // (measured: with their 6-row bands bursts of 2 change nothing, bursts of 3 or 4 cost 3..5 %)
+#endif
+
 // Common prologue of the wave-march kernels: this wave's strip, band and I/O.
 #define MI_MARCH_PROLOGUE()                                                                      \
     const WaveJob j = wave_job(g);                                                               \
@@ -110,18 +115,21 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
     u32 t01, t23, m01, m23, b01, b23, th, mh, bh;
     // t = oldest row of the window, b = newest.  Marching up swaps their roles, which only flips
     // the sign of Gy; Gx^2 + Gy^2 does not change.
-    red_pairs(io.load(mch.row(-1)), t01, t23);
-    th = halo_red(io.load_halo1(mch.row(-1)));
-    red_pairs(io.load(mch.row(0)), m01, m23);
-    mh = halo_red(io.load_halo1(mch.row(0)));
-    u32x4 nxt = io.load(mch.row(1));
-    u32 nxh = io.load_halo1(mch.row(1));
+    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    feed.start(-1);
+    typename Feed::Row r = feed.next(0, 2);
+    red_pairs(r.p, t01, t23);
+    th = halo_red(r.h);
+    r = feed.next(1, 2);
+    red_pairs(r.p, m01, m23);
+    mh = halo_red(r.h);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
-        red_pairs(nxt, b01, b23);
-        bh = halo_red(nxh);
-        nxt = io.load(mch.row(i + 2));   // one row ahead; deeper prefetch measured no gain
-        nxh = io.load_halo1(mch.row(i + 2));
+        r = feed.next(i + 2, 2);         // row i + 1; the rows of the next steps are requested in bursts
+        red_pairs(r.p, b01, b23);
+        bh = halo_red(r.h);
         const u32 V01 = pk_add(pk_add(t01, b01), pk_add(m01, m01));
         const u32 V23 = pk_add(pk_add(t23, b23), pk_add(m23, m23));
         const u32 VH = pk_add(pk_add(th, bh), pk_add(mh, mh));
@@ -236,15 +244,18 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    hsum(io.load(mch.row(-1)), io.load_halo1(mch.row(-1)), tl, th);
-    hsum(io.load(mch.row(0)), io.load_halo1(mch.row(0)), ml, mh);
-    u32x4 nxt = io.load(mch.row(1));
-    u32 nxh = io.load_halo1(mch.row(1));
+    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    feed.start(-1);
+    typename Feed::Row r = feed.next(0, 2);
+    hsum(r.p, r.h, tl, th);
+    r = feed.next(1, 2);
+    hsum(r.p, r.h, ml, mh);
     for (int i = 0; i < mch.n; i++) {
         const int y = mch.row(i);
-        hsum(nxt, nxh, bl, bh);
-        nxt = io.load(mch.row(i + 2));
-        nxh = io.load_halo1(mch.row(i + 2));
+        r = feed.next(i + 2, 2);
+        hsum(r.p, r.h, bl, bh);
         const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
         u32 o[4];
 #pragma unroll
@@ -304,19 +315,22 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
     };
 
     u32 win[3][8];
-    unpack(io.load(mch.row(-1)), io.load_halo1(mch.row(-1)), win[0]);
-    unpack(io.load(mch.row(0)), io.load_halo1(mch.row(0)), win[1]);
-    u32x4 nxt = io.load(mch.row(1));
-    u32 nxh = io.load_halo1(mch.row(1));
+    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    feed.start(-1);
+    typename Feed::Row r = feed.next(0, 2);
+    unpack(r.p, r.h, win[0]);
+    r = feed.next(1, 2);
+    unpack(r.p, r.h, win[1]);
     for (int base = 0; base < mch.n; base += 3) {
 #pragma unroll
         for (int s = 0; s < 3; s++) {
             const int i = base + s;
             if (i < mch.n) {
             const int y = mch.row(i);
-            unpack(nxt, nxh, win[(s + 2) % 3]);          // input step i+1
-            nxt = io.load(mch.row(i + 2));
-            nxh = io.load_halo1(mch.row(i + 2));
+            r = feed.next(i + 2, 2);
+            unpack(r.p, r.h, win[(s + 2) % 3]);          // input step i+1
             // sort every 3-pixel column: lo <= mid <= hi
             u32 lo[8], mid[8], hi[8];
 #pragma unroll
@@ -729,8 +743,8 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
                                                     u32* __restrict__ out, const Geo g,
                                                     const GaussW gw)
 {
-    // per wave: a ring of 2 * MI_CHAIN_BURST input rows of 1 KiB (see `run` below)
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[(POL == 1 && MI_CHAIN_BURST > 0) ? 4 * 2 * MI_CHAIN_BURST * 1024 : 16];
+    typedef RowFeed<POL, MI_CHAIN_BURST, false> Feed;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     const WaveJob j = wave_job(g);
     if (!j.valid) return;
     constexpr int OUTW = 4 * (64 - 2 * MRG);
@@ -790,40 +804,12 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
     // How the input rows arrive.  With its arithmetic removed this kernel took the same time as with it:
     // it was bound by the shape of its memory accesses -- one row per step requested by each of thousands of
     // bands.  As a pure copy that shape runs at 4.9 TB/s; requesting K consecutive rows of the strip at one
-    // time runs at 5.4 (tools/marchbench.hip, profiles/r02_marchbench.txt).  So (aligned images) the wave
-    // requests its rows in BURSTS of K = MI_CHAIN_BURST, every K steps, for the NEXT K steps, straight into
-    // a ring of 2K rows in LDS (buffer_load ... lds: no registers are held by rows in flight, the occupancy
-    // stays at six waves per SIMD) and reads one row back per step.  hipcc does not order a ds_read behind
-    // an LDS-DMA write, so the wait is explicit: vector-memory operations complete in order, and after a
-    // burst is issued the only younger ones than the previous burst are the K stores of the steps in
-    // between and the K loads just issued -- s_waitcnt vmcnt(2K) (vmcnt(K) for the first bursts of a band,
-    // which have fewer stores before them) means "the rows of the next K steps have landed".
-    constexpr bool LDSQ = POL == 1 && MI_CHAIN_BURST > 0;
-    constexpr int K = MI_CHAIN_BURST > 0 ? MI_CHAIN_BURST : 1;
-    [[maybe_unused]] unsigned char* myring = nullptr;
-    u32x4 nxt = {0u, 0u, 0u, 0u};
-    auto dma_row = [&](int row, int slot) {
-#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass only needs the kernel's stub)
-        if constexpr (POL == 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(myring + slot * 1024), 16,
-                                                     (row - io.row0) * io.pitch + io.in_off, 0, 0, 0);
-#endif
-    };
-    auto wait_vm = [](auto n) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n)::value) : "memory");
-#endif
-    };
+    // time runs at 5.4 (tools/marchbench.hip, profiles/r02_marchbench.txt).  RowFeed (common.h) does that:
+    // bursts of K = MI_CHAIN_BURST rows straight into a per-wave ring in LDS, one row read back per step.
+    Feed feed(io, mch, ring, j.lane);
 #pragma unroll
     for (int i = 0; i < 4; i++) gray_hrow(io.load(mch.row(i - 4)), win[i]);
-    if constexpr (LDSQ) {
-        myring = ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (2 * K * 1024);
-#pragma unroll
-        for (int p = 0; p < K; p++) dma_row(mch.row(p), p);
-    } else {
-        nxt = io.load(mch.row(0));
-    }
-    int phase = 0, slot = 0;     // step i: phase = i % K, slot = i % 2K (wave-uniform)
+    feed.start(0);
 
     const int steps = mch.n + 4;   // input steps 0 .. n+3; step i completes output row i-4
     for (int base = 0; base < steps; base += 5) {
@@ -831,24 +817,7 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
         for (int s = 0; s < 5; s++) {
             const int i = base + s;
             if (i < steps) {
-            u32x4 cur;
-            if constexpr (LDSQ) {
-                if (phase == 0) {
-                    const int first = slot >= K ? 0 : K;          // the half of the ring the last K steps have read
-#pragma unroll
-                    for (int p = 0; p < K; p++) dma_row(mch.row(i + K + p), first + p);
-                    // (steps 0..3 store nothing: until step 4 + K the count of stores in between is below K;
-                    // waiting for more than necessary is always safe)
-                    if (i < 4 + K) wait_vm(std::integral_constant<int, K>{});
-                    else wait_vm(std::integral_constant<int, 2 * K>{});
-                }
-                cur = *reinterpret_cast<const u32x4*>(myring + slot * 1024 + 16 * j.lane);
-                phase = phase + 1 == K ? 0 : phase + 1;
-                slot = slot + 1 == 2 * K ? 0 : slot + 1;
-            } else {
-                cur = nxt;
-                if (MI_CHAIN_DBG != 6 || g.batch < 0) nxt = io.load(mch.row(i + 1));
-            }
+            const u32x4 cur = feed.next(i, 4).p;      // (the first store is step 4's)
             if constexpr (MI_CHAIN_DBG == 1) {
                 if (i >= 4) io.store(mch.row(i - 4), cur);
                 continue;

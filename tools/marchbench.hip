@@ -169,6 +169,12 @@ static float dispatch(const u32* in, u32* out, const Geo& g, const Cfg& c, int r
 #undef BC
         return -1.f;
     }
+    if (c.vec >= 10 && c.mrg == 0) {
+#define BC(KK) if (c.pf == KK) return run_burst<KK, 0, 0>(in, out, g, c, reps);
+        BC(2) BC(3) BC(4) BC(6) BC(8)
+#undef BC
+        return -1.f;
+    }
 #define CASE(P, M) if (c.pf == P && c.mrg == M) return run_aux<P, M>(in, out, g, c, reps);
     CASE(1, 0) CASE(2, 0) CASE(3, 0) CASE(4, 0) CASE(6, 0)
     CASE(1, 1) CASE(2, 1) CASE(3, 1) CASE(4, 1)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""ms per launch of the single-filter kernels (and the fused chain) on the bench workload, 16 x 3840x2160.
+Usage: python tools/time_filters.py [name ...]   (default: all)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from cudaimageprocessing_amd import ops
+
+W, H, B = 3840, 2160, 16
+frames = ops.synth(2, W, H, batch=B)
+out = torch.empty_like(frames)
+F = {
+    "gray": lambda: ops.grayscale(frames, out),
+    "sobel": lambda: ops.sobel(frames, out),
+    "mean3": lambda: ops.mean_blur(frames, 3, out),
+    "median3": lambda: ops.median_blur(frames, 3, out),
+    "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
+    "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),
+    "gauss9": lambda: ops.gaussian_blur(frames, 9, 2.0, out),
+    "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
+    "mean7": lambda: ops.mean_blur(frames, 7, out),
+    "mean15": lambda: ops.mean_blur(frames, 15, out),
+    "median5": lambda: ops.median_blur(frames, 5, out),
+    "chain": lambda: ops.fused_chain(frames, 1.0, out),
+}
+names = sys.argv[1:] or list(F)
+
+def timed(fn, n=200):
+    for _ in range(30):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+for _ in range(400):
+    F["chain"]()
+torch.cuda.synchronize()
+cells = []
+for nme in names:
+    t = min(timed(F[nme]), timed(F[nme]))
+    cells.append(f"{nme} {t:.4f} ({B * W * H * 8 / (t * 1e-3) / 8e12:.3f})")
+print("  ".join(cells), flush=True)

@@ -9,10 +9,16 @@ tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 out=$root/gpurun_out
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --no-cpu-baseline > $out/${tag}_stats.log 2>&1 || { echo "stats pass failed"; tail -5 $out/${tag}_stats.log; exit 1; }
+# (--legs '': the C3 leg launches the same chain kernel on 4096 frames, which would mix two launch sizes into one average)
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --no-cpu-baseline --legs '' > $out/${tag}_stats.log 2>&1 || { echo "stats pass failed"; tail -5 $out/${tag}_stats.log; exit 1; }
+# the other configurations' kernels (C3, C4, C5 legs), few C2 steps
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_legs_stats -- python3 $root/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $out/${tag}_legs_stats.log 2>&1 || { echo "legs stats pass failed"; tail -5 $out/${tag}_legs_stats.log; exit 1; }
+grep -h '^{"metric' $out/${tag}_legs_stats.log > $out/${tag}_bench_legs_line_profiled.json
+f=$(find $out/${tag}_legs_stats -name '*kernel_stats.csv' | head -1)
+cp "$f" $out/${tag}_legs_kernel_stats.csv
 grep -h '^{"metric' $out/${tag}_stats.log > $out/${tag}_bench_line_profiled.json   # bench.py's own line from the profiled process
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/${tag}_pmc_$c.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs '' > $out/${tag}_pmc_$c.log 2>&1 || { echo "pass $c failed"; tail -5 $out/${tag}_pmc_$c.log; exit 1; }
 done
 python3 $root/tools/pmc_summary.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE --json $out/${tag}_traffic.json > $out/${tag}_traffic.txt
 cat $out/${tag}_traffic.txt

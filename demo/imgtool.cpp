@@ -2,16 +2,18 @@
 // against include/imageTools.h: the same wrapper calls on (img, img), with the file names and
 // the list of operations taken from the command line instead of being edited into the source.
 //
-//   imgtool <in.png|in.ppm|in.pgm> <out.png> [--ops gray,gauss:5:1.0,median:3,sobel] [--one-trip]
+//   imgtool <in.jpg|in.png|in.ppm|...> <out.png> [--ops gray,gauss:5:1.0,median:3,sobel] [--one-trip]
+//   imgtool --decode <in> <out.png>      decode only (stb_image, like the reference's loadImage), no GPU work
 //   imgtool --selftest
 //
 // ops: gray | sobel | gauss:K:SIGMA | mean[:K] | median[:K] | fft_highpass | compress[:KEEP]
 // (mean:K with K != 3 and compress:KEEP go through the C ABI, which has the parameters the
 // reference's signatures lack).  --one-trip sends runs of consecutive pixel filters through
 // mi_run_ops_u8x4 (one PCIe round trip per run instead of one per filter); the pixels are the same.
-// The output is always a PNG, as with the reference (imageTools.cu:152).  JPEG decoding is not
-// built in (upstream used the stb_image header for it): use `python -m cudaimageprocessing_amd.cli`,
-// which decodes with Pillow, or convert to PNG/PPM first.
+// The output is always a PNG, as with the reference (imageTools.cu:152).  Inputs are decoded as the
+// reference decodes them -- stbi_load(..., STBI_rgb_alpha), main.cpp:14, with the same stb_image v2.30
+// (third_party/stb/, unchanged) -- so a JPEG gives the same RGBA bytes as upstream; PNG and PNM inputs
+// keep this file's own small decoders (stb would give the same pixels).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +22,10 @@
 
 #include <string>
 #include <vector>
+
+#define STB_IMAGE_IMPLEMENTATION
+#define STBI_NO_SIMD   // (the scalar and SIMD paths of stb_image give identical pixels; no SIMD keeps hipcc's host pass simple)
+#include "../third_party/stb/stb_image.h"
 
 #include "../include/imageTools.h"
 #include "../include/mi_imagetools.h"
@@ -123,15 +129,25 @@ std::vector<uint8_t> decode_pnm(const std::vector<uint8_t>& d, int* w, int* h)
     return px;
 }
 
+// File -> RGBA bytes.
+std::vector<uint8_t> decode_file(const char* path, int* w, int* h)
+{
+    const std::vector<uint8_t> d = read_file(path);
+    if (d.size() > 8 && !memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8)) return decode_png(d, w, h);
+    if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return decode_pnm(d, w, h);
+    // everything else (JPEG first of all) the way the reference's loadImage does it (main.cpp:12-19)
+    int channels = 0;
+    unsigned char* img = stbi_load_from_memory(d.data(), (int)d.size(), w, h, &channels, STBI_rgb_alpha);
+    if (!img) die(std::string("unknown image format: ") + path + " (" + stbi_failure_reason() + ")");
+    std::vector<uint8_t> rgba(img, img + (size_t)*w * *h * 4);
+    stbi_image_free(img);
+    return rgba;
+}
+
 // Decoded file -> the library's pixel layout, through imageLoadWrapper as upstream (main.cpp:20-22).
 uchar4* load_image(const char* path, int* w, int* h)
 {
-    const std::vector<uint8_t> d = read_file(path);
-    std::vector<uint8_t> rgba;
-    if (d.size() > 8 && !memcmp(d.data(), "\x89PNG\r\n\x1a\n", 8)) rgba = decode_png(d, w, h);
-    else if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) rgba = decode_pnm(d, w, h);
-    else if (d.size() > 2 && d[0] == 0xFF && d[1] == 0xD8) die("JPEG input: decode it with `python -m cudaimageprocessing_amd.cli` or convert to PNG/PPM");
-    else die(std::string("unknown image format: ") + path);
+    std::vector<uint8_t> rgba = decode_file(path, w, h);
     const size_t n = (size_t)*w * *h;
     uchar4* img = new uchar4[n];
     imageLoadWrapper(rgba.data(), img, n);
@@ -205,6 +221,13 @@ int main(int argc, char** argv)
         printf("self-test %s\n", ok ? "passed" : "FAILED");
         return ok ? 0 : 1;
     }
+    if (argc == 4 && !strcmp(argv[1], "--decode")) {
+        int w = 0, h = 0;
+        const std::vector<uint8_t> rgba = decode_file(argv[2], &w, &h);
+        check(mi_image_write(argv[3], rgba.data(), w, h), "write");
+        printf("decoded %s: %d x %d\n", argv[2], w, h);
+        return 0;
+    }
     const char *in = nullptr, *out = nullptr;
     std::string spec = "fft_highpass";   // what the reference's main.cpp runs as checked in
     bool one_trip = false;
@@ -215,7 +238,7 @@ int main(int argc, char** argv)
         else if (!out) out = argv[i];
         else die(std::string("unexpected argument ") + argv[i]);
     }
-    if (!in || !out) die("usage: imgtool <in.png|in.ppm> <out.png> [--ops LIST] [--one-trip] | imgtool --selftest");
+    if (!in || !out) die("usage: imgtool <in> <out.png> [--ops LIST] [--one-trip] | imgtool --decode <in> <out.png> | imgtool --selftest");
     int w = 0, h = 0;
     uchar4* img = load_image(in, &w, &h);
     printf("loaded %s: %d x %d\n", in, w, h);

@@ -112,3 +112,21 @@ def test_missing_gpu_fails_loudly(mi):
     b = np.zeros_like(a)
     rc = mi.lib().mi_grayscale_u8x4(a.ctypes.data, b.ctypes.data, 4, 4)
     assert rc > 0 and "HIP error" in mi.last_error()
+
+
+def test_imgtool_decodes_jpeg_like_the_committed_stb_fixture(tmp_path):
+    """demo/imgtool --decode is stb_image v2.30's decoder (what the reference's loadImage calls, main.cpp:14);
+    tests/golden/lord_decoded_by_stb.png was made with it.  Needs no GPU."""
+    import subprocess
+    Image = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "demo", "imgtool")
+    if not os.path.exists(tool):
+        pytest.skip("demo/imgtool not built")
+    dst = str(tmp_path / "lord.png")
+    p = subprocess.run([tool, "--decode", os.path.join(root, "tests", "golden", "lord.jpeg"), dst], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = np.asarray(Image.open(dst).convert("RGB"))
+    want = np.asarray(Image.open(os.path.join(root, "tests", "golden", "lord_decoded_by_stb.png")).convert("RGB"))
+    assert np.array_equal(got, want)
+

@@ -76,10 +76,14 @@ def test_fft_highpass_reproduces_the_upstream_sample_output(dev):
     """imageFFTImageGenerate on the reference's own demo input against the reference's own output
     (tests/golden/lord.jpeg -> tests/golden/upstream_output_of_lord.png, see tests/test_oracle.py): the
     675x900 image goes through the chirp-z path and through the reference's cufftPlan2d(width, height)
-    geometry.  Pillow decodes the JPEG here, stb_image did upstream: almost every byte identical."""
+    geometry.  The input is the stb_image decode upstream used: fp32 transforms here and in cuFFT, so a few
+    values that sit on a truncation boundary differ by one level; nothing differs by more."""
     Image = pytest.importorskip("PIL.Image")
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(here, "lord.jpeg")).convert("RGBA")))
+    # lord.jpeg decoded by stb_image v2.30 as the reference decodes it (main.cpp:14): `demo/imgtool --decode
+    # tests/golden/lord.jpeg x.png`, re-saved as an RGB PNG (a data fixture; Pillow's JPEG decoder differs from
+    # stb's on 1.3 % of the bytes, which used to cap this comparison at 98.4 % identical)
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(here, "lord_decoded_by_stb.png")).convert("RGBA")))
     want = np.asarray(Image.open(os.path.join(here, "upstream_output_of_lord.png")))
     h, w = img.shape[:2]
     out = np.empty_like(img)
@@ -87,7 +91,7 @@ def test_fft_highpass_reproduces_the_upstream_sample_output(dev):
     assert np.array_equal(out[..., 3], want[..., 3])
     d = np.abs(out[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
     print(f"identical {100 * (d == 0).mean():.2f} %, within 1: {100 * (d <= 1).mean():.2f} %, max {d.max()}")
-    assert (d == 0).mean() >= 0.97 and (d <= 1).mean() >= 0.995 and d.max() <= 4
+    assert (d == 0).mean() >= 0.9999 and d.max() <= 1
     # in place, as the reference's main.cpp calls it (main.cpp:43)
     buf = img.copy()
     ops.imageFFTImageGenerate(buf, buf, w, h)

@@ -410,17 +410,21 @@ def test_oracle_reproduces_committed_vectors(golden):
 def test_fft_highpass_reproduces_the_upstream_sample_output(golden):
     """The one output the reference's authors left behind: image/output.jpg (a 675x900 RGBA PNG), made by
     their main.cpp (imageFFTImageGenerate, cutoff 10) from image/lord.jpeg on their GPU; both files are
-    committed under tests/golden/ as data.  The oracle must reproduce it.  The input is decoded with Pillow
-    here, upstream used stb_image (the two JPEG decoders differ by an LSB on some pixels), so the bar is
-    'almost every byte identical, none far off': measured 98.4 % identical, 99.9 % within 1, max 3.
+    committed under tests/golden/ as data.  The oracle must reproduce it.  With the input decoded as upstream
+    decoded it (stb_image) the oracle's output is byte-identical to the reference's on 99.999 % of the
+    1.8 million colour bytes and never more than one level off (cuFFT vs a double-precision DFT: values
+    that sit on a truncation boundary).
     With the mathematically correct 2-D geometry (rows = height) instead of the reference's
     cufftPlan2d(width, height), only 31 % of the bytes agree and the mean error is 16 levels."""
     Image = pytest.importorskip("PIL.Image")
     here = os.path.join(os.path.dirname(__file__), "golden")
-    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(here, "lord.jpeg")).convert("RGBA")))
+    # lord.jpeg decoded by stb_image v2.30 as the reference decodes it (main.cpp:14): `demo/imgtool --decode
+    # tests/golden/lord.jpeg x.png`, re-saved as an RGB PNG (a data fixture; Pillow's JPEG decoder differs from
+    # stb's on 1.3 % of the bytes, which used to cap this comparison at 98.4 % identical)
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(here, "lord_decoded_by_stb.png")).convert("RGBA")))
     want = np.asarray(Image.open(os.path.join(here, "upstream_output_of_lord.png")))
     assert img.shape == (900, 675, 4) and want.shape == (900, 675, 4)
     got, _ = golden.fft_highpass_image(img, 10.0)
     assert np.array_equal(got[..., 3], want[..., 3])
     d = np.abs(got[..., :3].astype(np.int16) - want[..., :3].astype(np.int16))
-    assert (d == 0).mean() >= 0.97 and (d <= 1).mean() >= 0.995 and d.max() <= 4
+    assert (d == 0).mean() >= 0.9999 and d.max() <= 1

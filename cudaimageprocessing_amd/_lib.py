@@ -51,6 +51,8 @@ SIGNATURES = {
     "mi_medianblur_u8x4": [_vp, _vp, _i, _i, _i],
     "mi_run_ops_u8x4": [_vp, _vp, _i, _i, _vp, _i],
     "mi_run_ops_chunked_u8x4": [_vp, _vp, _i, _i, _vp, _i, _i],
+    "mi_batch_run_ops_u8x4": [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i],
+    "mi_strip_run_ops_u8x4": [_vp, _vp, _i, _i, _vp, _i, _vp, _i],
     "mi_host_release": [],
     "mi_fft_highpass_u8x4": [_vp, _vp, _i, _i, _f],
     "mi_fft_highpass_workspace_bytes": [_i, _i, _vp],

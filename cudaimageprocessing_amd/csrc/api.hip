@@ -507,6 +507,51 @@ int mi_run_ops_chunked_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const
     return run_host_ops(in, out, w, h, ops, n_ops, chunk_rows);
 }
 
+static int check_devices(const int* devices, int n_devices)
+{
+    if (!devices || n_devices <= 0 || n_devices > 64) return fail(MI_ERR_INVALID_ARG, "need 1..64 devices");
+    const int count = mi_device_count();
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= count) return fail(MI_ERR_INVALID_ARG, "device %d of %d visible", devices[i], count);
+    return MI_OK;
+}
+
+static int check_ops(int w, int h, const mi_op* ops, int n_ops)
+{
+    if (!ops || n_ops <= 0 || n_ops > MI_MAX_OPS) return fail(MI_ERR_INVALID_ARG, "need 1..%d ops (got %d)", MI_MAX_OPS, n_ops);
+    for (int k = 0; k < n_ops; k++) {
+        const int rc = check_filter(ops[k].filter, w, h, ops[k].ksize, ops[k].sigma);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
+int mi_batch_run_ops_u8x4(const uint8_t* in, uint8_t* out, int w, int h, int n_frames, const mi_op* ops, int n_ops,
+                          const int* devices, int n_devices)
+{
+    int rc = check_image(in, out, w, h, n_frames);
+    if (rc == MI_OK) rc = check_ops(w, h, ops, n_ops);
+    if (rc == MI_OK) rc = check_devices(devices, n_devices);
+    if (rc) return rc;
+    const size_t bytes = (size_t)w * h * 4 * n_frames;
+    if (in != out && overlap(in, bytes, out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping host buffers");
+    return host_batch_run(in, out, w, h, n_frames, ops, n_ops, devices, n_devices);
+}
+
+int mi_strip_run_ops_u8x4(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, const int* devices,
+                          int n_devices)
+{
+    int rc = check_image(in, out, w, h, 1);
+    if (rc == MI_OK) rc = check_ops(w, h, ops, n_ops);
+    if (rc == MI_OK) rc = check_devices(devices, n_devices);
+    if (rc) return rc;
+    const size_t bytes = (size_t)w * h * 4;
+    // strips run concurrently and read each other's rows of `in` as halo: in place only on one device
+    if (overlap(in, bytes, out, bytes) && !(in == out && n_devices == 1))
+        return fail(MI_ERR_OVERLAP, "mi_strip_run_ops_u8x4 on several devices needs out != in");
+    return host_strip_run(in, out, w, h, ops, n_ops, devices, n_devices);
+}
+
 int mi_host_release(void) { return host_release(); }
 
 // imageFFTImageGenerate's scaffold (imageTools.cu:633-791): u8 -> three complex planes -> forward

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -157,6 +158,14 @@ int host_scratch(size_t bytes, HostScratch* out)
 // ops are validated by the caller (api.hip).
 int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows_hint)
 {
+    return host_run_ops_rows(in, out, w, h, ops, n_ops, chunk_rows_hint, 0, h);
+}
+
+// Output rows [y0, y1) of the filtered image only (`in` and `out` are whole images): the piece of the work one
+// device does when an image is split into row strips; the halo rows come straight from the host image.
+int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows_hint,
+                      int y0, int y1)
+{
     const size_t pitch = (size_t)w * 4;
     int halo_sum = 0;
     for (int k = 0; k < n_ops; k++) halo_sum += filter_halo_rows(ops[k].filter, ops[k].ksize);
@@ -164,8 +173,8 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     // chunk's input never reaches into rows an earlier chunk may already have overwritten when
     // `out` aliases `in`, see below)
     int chunk = chunk_rows_hint > 0 ? chunk_rows_hint : (int)std::max<size_t>(1, ((size_t)8 << 20) / pitch);
-    chunk = std::min(h, std::max(chunk, std::max(halo_sum, 1)));
-    const int n_chunks = (h + chunk - 1) / chunk;
+    chunk = std::min(y1 - y0, std::max(chunk, std::max(halo_sum, 1)));
+    const int n_chunks = (y1 - y0 + chunk - 1) / chunk;
     const size_t in_rows_max = (size_t)std::min(h, chunk + 2 * halo_sum);
 
     int device = 0;
@@ -211,7 +220,7 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
             std::this_thread::yield();
         if (abort_flag.load(std::memory_order_acquire)) break;
         // rows each stage must produce, back to front
-        need[n_ops] = Rows{c * chunk, std::min(h, (c + 1) * chunk)};
+        need[n_ops] = Rows{y0 + c * chunk, std::min(y1, y0 + (c + 1) * chunk)};
         for (int k = n_ops - 1; k >= 0; k--) {
             const int halo = filter_halo_rows(ops[k].filter, ops[k].ksize);
             need[k] = Rows{std::max(0, need[k + 1].lo - halo), std::min(h, need[k + 1].hi + halo)};
@@ -246,6 +255,55 @@ int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops
     }
     if (rc) return rc;
     return hip_status(e, "host-tier filter pipeline");
+}
+
+// ---------------------------------------------------------------- several devices, one process
+// One host thread per entry of `devices` (an ordinal may repeat: its threads then take turns on that
+// device's pipe).  work(d, index) runs with device devices[index] current; the first failure wins
+// and its message is handed to the calling thread.
+template <class Work>
+static int run_on_devices(const int* devices, int n_devices, Work work)
+{
+    int keep = 0;
+    const bool have = hipGetDevice(&keep) == hipSuccess;
+    std::vector<int> rcs(n_devices, MI_OK);
+    std::vector<std::string> msgs(n_devices);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n_devices; i++)
+        threads.emplace_back([&, i] {
+            const hipError_t e = hipSetDevice(devices[i]);
+            rcs[i] = e == hipSuccess ? work(i) : hip_status(e, "hipSetDevice");
+            if (rcs[i] != MI_OK) msgs[i] = mi_last_error();      // the error text is per thread
+        });
+    for (std::thread& t : threads) t.join();
+    if (have) (void)hipSetDevice(keep);
+    for (int i = 0; i < n_devices; i++)
+        if (rcs[i] != MI_OK) return fail(rcs[i], "device %d: %s", devices[i], msgs[i].c_str());
+    return MI_OK;
+}
+
+int host_batch_run(const uint8_t* in, uint8_t* out, int w, int h, int n_frames, const mi_op* ops, int n_ops,
+                   const int* devices, int n_devices)
+{
+    const size_t frame = (size_t)w * h * 4;
+    const int per = (n_frames + n_devices - 1) / n_devices;       // contiguous ceil(n/G) frames per device
+    return run_on_devices(devices, n_devices, [&](int i) {
+        const int f0 = std::min(n_frames, i * per), f1 = std::min(n_frames, f0 + per);
+        for (int f = f0; f < f1; f++) {
+            const int rc = host_run_ops(in + (size_t)f * frame, out + (size_t)f * frame, w, h, ops, n_ops, 0);
+            if (rc) return rc;
+        }
+        return (int)MI_OK;
+    });
+}
+
+int host_strip_run(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, const int* devices, int n_devices)
+{
+    return run_on_devices(devices, n_devices, [&](int i) {
+        const int y0 = (int)((int64_t)h * i / n_devices), y1 = (int)((int64_t)h * (i + 1) / n_devices);
+        if (y0 >= y1) return (int)MI_OK;
+        return host_run_ops_rows(in, out, w, h, ops, n_ops, 0, y0, y1);
+    });
 }
 
 }  // namespace mi

@@ -67,6 +67,13 @@ int launch_sobel_pairs(void* out, int gmax, int variant, hipStream_t s);
 // chunk_rows_hint <= 0 picks the chunk height.  host_release frees the cached buffers.
 int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops,
                  int chunk_rows_hint);
+int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops,
+                      int chunk_rows_hint, int y0, int y1);
+// one process, several devices (one host thread each): frames / row strips of a host image
+int host_batch_run(const uint8_t* in, uint8_t* out, int w, int h, int n_frames, const mi_op* ops, int n_ops,
+                   const int* devices, int n_devices);
+int host_strip_run(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, const int* devices,
+                   int n_devices);
 int host_release();
 // Device scratch of at least `bytes` for a blocking host-tier call, kept between calls (freed by
 // host_release).  The holder of `lock` owns the buffer: host-tier spectral calls serialise on it.

@@ -381,6 +381,28 @@ def run_ops(returnImage, imageLoaded, width, height, ops_list, chunk_rows=None):
         check(lib().mi_run_ops_chunked_u8x4(src, dst, width, height, arr, len(ops_list), int(chunk_rows)))
 
 
+def _op_array(ops_list):
+    if isinstance(ops_list, str):
+        ops_list = parse_ops(ops_list)
+    return (_lib.Op * len(ops_list))(*[_lib.Op(int(f), int(k), float(s)) for f, k, s in ops_list]), len(ops_list)
+
+
+def batch_run_ops(out, frames, ops_list, devices=(0,)):
+    """mi_batch_run_ops_u8x4: host frames (n, h, w, 4) sharded by frame over `devices` (one process)."""
+    n, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    arr, n_ops = _op_array(ops_list)
+    dev = (C.c_int * len(devices))(*devices)
+    check(lib().mi_batch_run_ops_u8x4(frames.ctypes.data, out.ctypes.data, w, h, n, arr, n_ops, dev, len(devices)))
+
+
+def strip_run_ops(out, image, ops_list, devices=(0,)):
+    """mi_strip_run_ops_u8x4: one host image (h, w, 4) in row strips over `devices` (one process)."""
+    h, w = int(image.shape[0]), int(image.shape[1])
+    arr, n_ops = _op_array(ops_list)
+    dev = (C.c_int * len(devices))(*devices)
+    check(lib().mi_strip_run_ops_u8x4(image.ctypes.data, out.ctypes.data, w, h, arr, n_ops, dev, len(devices)))
+
+
 def fft_highpass_workspace_bytes(width, height, batch=1):
     n = C.c_size_t(0)
     check(lib().mi_fft_highpass_batch_workspace_bytes(int(width), int(height), int(batch), C.byref(n)))

@@ -214,6 +214,20 @@ int mi_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *
 /* The same with the chunk height chosen by the caller (tests; tuning). */
 int mi_run_ops_chunked_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *ops,
                             int n_ops, int chunk_rows);
+/* Several GPUs behind the C ABI, one process (no counterpart upstream: the reference is single-GPU;
+ * BASELINE.json configs 3 and 4).  One host thread per entry of `devices` (HIP ordinals; an ordinal
+ * may repeat), each driving its device's own staging pipeline; nothing is exchanged between devices
+ * because every halo row comes from the host image.  The pixels are those of mi_run_ops_u8x4.
+ *   mi_batch_run_ops_u8x4  n_frames images of w x h back to back; device i takes the contiguous
+ *                          frames [i*ceil(n/G), (i+1)*ceil(n/G)); out may be in.
+ *   mi_strip_run_ops_u8x4  one image; device i filters rows [h*i/G, h*(i+1)/G) (its chunks read
+ *                          the accumulated halo of the list from `in`); out must not be in when G > 1.
+ * The calling thread's current device is unchanged on return.  (Device-resident strips with an RCCL
+ * halo exchange are cudaimageprocessing_amd/shard.py over mi_filter_strip_u8x4_dev.) */
+int mi_batch_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int n_frames, const mi_op *ops,
+                          int n_ops, const int *devices, int n_devices);
+int mi_strip_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *ops, int n_ops,
+                          const int *devices, int n_devices);
 int mi_host_release(void);
 /* imageFFTImageGenerate (imageTools.cu:633-791) without its debug means; cutoff is the
  * reference's hard-coded 10.0f (:716).  The transforms use the reference's plan geometry,

@@ -189,3 +189,38 @@ def test_host_tier_calls_from_several_threads(dev):
         for rep in range(6):
             for x, y in zip(got[i][rep], want[i]):
                 assert np.array_equal(x, y)
+
+
+def test_multi_device_entry_points_of_the_c_abi(dev, golden):
+    """mi_batch_run_ops_u8x4 / mi_strip_run_ops_u8x4: one host thread per listed device.  This box has one
+    GPU, so ordinal 0 is listed one, two and three times (the threads take turns on its pipe): what is under
+    test is the partition into frames / row strips with their halos, against mi_run_ops_u8x4 and the oracle."""
+    spec = "gray,gauss_direct:5:1.0,median:3,sobel,mean:7,median:5"
+    w, h, n = 200, 157, 5
+    frames = np.stack([S.synth_image(40 + f, w, h) for f in range(n)])
+    want = np.empty_like(frames)
+    for f in range(n):
+        ops.run_ops(want[f], frames[f], w, h, spec)
+    ref = golden.medianblur(golden.meanblur(golden.sobel(golden.medianblur(golden.gaussian(golden.grayscale(frames[0]), 5, 1.0), 3)), 7), 5)
+    assert np.array_equal(want[0], ref)
+    for devices in ((0,), (0, 0), (0, 0, 0)):
+        out = np.zeros_like(frames)
+        ops.batch_run_ops(out, frames, spec, devices)
+        assert np.array_equal(out, want), devices
+        one = np.zeros_like(frames[0])
+        ops.strip_run_ops(one, frames[1], spec, devices)
+        assert np.array_equal(one, want[1]), devices
+    # in place: frames always, strips only on one device
+    buf = frames.copy()
+    ops.batch_run_ops(buf, buf, spec, (0, 0))
+    assert np.array_equal(buf, want)
+    buf = frames[2].copy()
+    ops.strip_run_ops(buf, buf, spec, (0,))
+    assert np.array_equal(buf, want[2])
+    with pytest.raises(_lib.MiError) as e:
+        ops.strip_run_ops(buf, buf, spec, (0, 0))
+    assert e.value.code == -4
+    with pytest.raises(_lib.MiError) as e:
+        ops.strip_run_ops(np.zeros_like(buf), buf, spec, (0, 7))
+    assert e.value.code == -1
+

@@ -49,6 +49,57 @@ __global__ __launch_bounds__(256) void lines_k(const float* __restrict__ in, flo
     }
 }
 
+// Whole-column tile: a block of 1024 lanes owns all 4096 rows of C adjacent columns (C = 4: 128 KiB of LDS in
+// the real kernel, so one block per CU; global accesses are runs of C * 8 bytes at a 32 KiB stride) and moves
+// them with 16-byte accesses, every load of the tile issued before the first store -- the shape a single-pass
+// column transform would have.  REMAP: the 128 / (8 C) tiles that share a 128-byte line get consecutive slots
+// on ONE XCD (blocks b, b+8, b+16, ... share an XCD) so that they meet in that XCD's L2.
+template <int C, bool REMAP>
+__global__ __launch_bounds__(1024) void coltile_k(const float* __restrict__ in, float* __restrict__ out, int total_tiles)
+{
+    extern __shared__ float occupancy_pad[];
+    constexpr int LPR = C * 8 / 16;                 // lanes per row run
+    constexpr int PTS = 4096 * LPR / 1024;          // 16-byte accesses per lane
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const unsigned tile = REMAP ? (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx : b;
+    if ((int)tile >= total_tiles) return;
+    constexpr int TPP = 4096 / C;                   // tiles per plane
+    const i64 plane = tile / TPP, cg = tile % TPP;
+    const int t = threadIdx.x;
+    f4 v[PTS];
+#pragma unroll
+    for (int k = 0; k < PTS; k++) {
+        const i64 row = plane * 4096 + t / LPR + (1024 / LPR) * k;
+        v[k] = *(const f4*)(in + (row * 4096 + cg * C) * 2 + (t % LPR) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < PTS; k++) {
+        const i64 row = plane * 4096 + t / LPR + (1024 / LPR) * k;
+        *(f4*)(out + (row * 4096 + cg * C) * 2 + (t % LPR) * 4) = v[k] * 2.0f;
+    }
+}
+
+template <int C, bool REMAP>
+void run_coltile(const char* name, const float* in, float* out, int planes, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tiles = planes * 4096 / C;
+    hipFuncSetAttribute((const void*)coltile_k<C, REMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 3; i++) coltile_k<C, REMAP><<<tiles, 1024, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) coltile_k<C, REMAP><<<tiles, 1024, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-52s lds %6d  %.3f ms  %.0f GB/s  (%s)\n", name, lds_bytes, ms, (double)planes * 4096 * 65536.0 / ms / 1e6,
+           hipGetErrorString(hipGetLastError()));
+}
+
 template <int V, bool COL, bool PERSIST>
 void run(const char* name, const float* in, float* out, int total_lines, int grid)
 {
@@ -81,6 +132,12 @@ int main()
         run<2, true, true>("col b64 persistent", in, out, total_lines, grid);
         run<4, true, true>("col b128 (1 KiB runs of 2 lanes/col) persistent", in, out, total_lines, grid);
     }
+    run_coltile<4, true>("whole-column tile, 4 columns (32-B runs), XCD remap", in, out, planes, 128 * 1024);
+    run_coltile<4, false>("whole-column tile, 4 columns (32-B runs), no remap", in, out, planes, 128 * 1024);
+    run_coltile<4, true>("whole-column tile, 4 columns, 2 blocks/CU (unreal)", in, out, planes, 64 * 1024);
+    run_coltile<2, true>("whole-column tile, 2 columns (16-B runs), XCD remap", in, out, planes, 64 * 1024);
+    run_coltile<2, false>("whole-column tile, 2 columns (16-B runs), no remap", in, out, planes, 64 * 1024);
+    run_coltile<8, true>("whole-column tile, 8 columns (64-B runs; 256 KiB: unreal)", in, out, planes, 128 * 1024);
     run<2, false, false>("row b64 one block per line", in, out, total_lines, 0);
     run<4, false, false>("row b128 one block per line", in, out, total_lines, 0);
     run<2, true, false>("col b64 one block per line", in, out, total_lines, 0);

@@ -515,6 +515,150 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
     }
 }
 
+// ============================================================================ Gaussian, separable, 11x11 .. 15x15
+// The kernel above keeps its window of K row-pass results as fp32: K x 12 registers per lane, 180 for
+// 15x15 -- the whole register file at two waves per SIMD, 79 of them spilled to scratch, and the vector
+// ALUs idle half the time (profiles/r02_valu_roofline.md).  Here the window is 16-bit fixed point, two
+// ROWS per register:
+//   * the row pass is the same fp32 sum, with its weights scaled by 256/65535, so that
+//     v_cvt_pknorm_u16_f32 (round(x * 65535), two values per instruction) turns two rows' results into
+//     a pair of 8.8 fixed-point values (h * 256, |error| <= 1/512);
+//   * arrivals 2j and 2j+1 (rows in marching order) share a register; a step's window is R + 1
+//     consecutive pairs -- (R + 1) x 12 registers, 96 for 15x15 -- whatever the parity of the step:
+//     an even step weights them (w0,w1) (w2,w3) .. (w2R,0), an odd one (0,w0) (w1,w2) .. (w2R-1,w2R);
+//   * the column pass is R + 1 v_dot2_u32_u16 per value with the weights as 0.16 fixed point whose sum is
+//     exactly 2^16 (the centre weight takes the rounding residue): the accumulator is the result in 8.24
+//     fixed point, its top byte the truncated output (imageTools.cu:306-308 truncates too).  Integer
+//     sums do not depend on the order: any decomposition into bands or strips gives the same bytes.
+// Error against the exact real-valued sum: 1/512 from the 8.8 rows + 255 * sum |w_t - wc_t / 2^16|
+// <= 255 * 2K * 2^-17 = 0.06 + the row pass's fp32 rounding (1e-4): < 0.07, far inside the
+// +-1 LSB the separable form is allowed; a constant image comes out exactly constant.
+struct GaussWide { float wr[16]; u32 wc_even[8]; u32 wc_odd[8]; };
+
+#ifndef MI_GW_WAVES
+#define MI_GW_WAVES 2
+#endif
+template <int R, int POL>
+__global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                            const Geo g, const GaussWide gw)
+{
+    constexpr int K = 2 * R + 1, NP = R + 1;
+    constexpr int HOPS = (R + 3) / 4;
+    constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;
+    MI_MARCH_PROLOGUE();
+
+    struct RowIn { u32x4 p, h1, h2; };
+    auto load_row = [&](int row) __attribute__((always_inline)) {
+        RowIn r;
+        r.p = io.load(row);
+        r.h1 = io.template load_halo_px<N1>(row, 1);
+        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
+        return r;
+    };
+    // row pass, as in gauss_sep_kernel: h[3*q+c] = the two adjacent outputs 2q, 2q+1 of channel c
+    auto hrow = [&](const RowIn& r, f32x2 (&h)[6]) __attribute__((always_inline)) {
+        u32 col[20];
+        const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
+        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[8 + k] = p[k];
+            col[4 + k] = from_left(p[k], k >= 4 - N1 ? a1[(k - (4 - N1)) & 3] : 0u);
+            col[12 + k] = from_right(p[k], k < N1 ? a1[k] : 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            col[k] = from_left(col[4 + k], (HOPS > 1 && k >= 4 - N2) ? a2[(k - (4 - N2)) & 3] : 0u);
+            col[16 + k] = from_right(col[12 + k], (HOPS > 1 && k < N2) ? a2[k] : 0u);
+        }
+        float f[4 + 2 * R][3];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * R; i++) {
+            const u32 v = col[8 - R + i];
+            f[i][0] = (float)(v & 0xffu);
+            f[i][1] = (float)((v >> 8) & 0xffu);
+            f[i][2] = (float)((v >> 16) & 0xffu);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                f32x2 s = splat2(gw.wr[0]) * f32x2{f[2 * q][c], f[2 * q + 1][c]};
+#pragma unroll
+                for (int t = 1; t < K; t++)
+                    s = __builtin_elementwise_fma(splat2(gw.wr[t]), f32x2{f[2 * q + t][c], f[2 * q + 1 + t][c]}, s);
+                h[3 * q + c] = s;
+            }
+    };
+    auto pk = [](float lo, float hi) { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pknorm_u16(lo, hi)); };
+
+    // win[slot][v]: pair j (arrivals 2j, 2j+1) lives in slot j % NP; v = 2 * (3q + c) + half
+    u32 win[NP][12];
+    f32x2 even[6];               // the row-pass result of the last even arrival, until its partner arrives
+#pragma unroll
+    for (int e = 0; e < 6; e++) even[e] = f32x2{0.f, 0.f};
+    auto arrive = [&](const RowIn& r, int a) __attribute__((always_inline)) {   // a = arrival index (static after unrolling)
+        f32x2 h[6];
+        hrow(r, h);
+        const int slot = (a / 2) % NP;
+        if (a % 2 == 0) {
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                even[e] = h[e];
+                win[slot][2 * e] = pk(h[e].x, 0.f);
+                win[slot][2 * e + 1] = pk(h[e].y, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 6; e++) {
+                win[slot][2 * e] = pk(even[e].x, h[e].x);
+                win[slot][2 * e + 1] = pk(even[e].y, h[e].y);
+            }
+        }
+    };
+    // arrivals 0 .. 2R-1 = input rows row(-R) .. row(R-1)
+#pragma unroll
+    for (int a = 0; a < 2 * R; a++) arrive(load_row(mch.row(a - R)), a);
+    RowIn nxt = load_row(mch.row(R));
+
+    constexpr int UNR = 2 * NP;      // pair slots and parities repeat with this period
+    for (int base = 0; base < mch.n; base += UNR) {
+#pragma unroll
+        for (int s = 0; s < UNR; s++) {
+            const int i = base + s;
+            if (i < mch.n) {
+            const int y = mch.row(i);
+            // arrival i + 2R (2R is even: its parity and, up to a constant, its slot are those of s)
+            arrive(nxt, s + 2 * R);
+            nxt = load_row(mch.row(i + R + 1));
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            // the window: pairs first .. first + R, first = floor(s / 2) (+ R * k, which the ring hides)
+            const u32* wc = (s % 2 == 0) ? gw.wc_even : gw.wc_odd;
+            u32 acc[12];
+#pragma unroll
+            for (int v = 0; v < 12; v++) {
+                u32 a = 0u;
+#pragma unroll
+                for (int t = 0; t < NP; t++)
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, win[(s / 2 + t) % NP][v]), __builtin_bit_cast(u16x2, wc[t]), a, false);
+                acc[v] = a;
+            }
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // acc index of pixel k, channel c: 2 * (3 * (k / 2) + c) + (k % 2); output byte = top byte
+                const u32 r8 = acc[2 * (3 * (k / 2) + 0) + (k % 2)], g8 = acc[2 * (3 * (k / 2) + 1) + (k % 2)],
+                          b8 = acc[2 * (3 * (k / 2) + 2) + (k % 2)];
+                const u32 rg = __builtin_amdgcn_perm(g8, r8, 0x0c0c0703u);          // (R, G, 0, 0)
+                o[k] = __builtin_amdgcn_perm(b8, rg, 0x0d070100u) & xm[k] & rowm;   // (R, G, B, 255)
+            }
+            io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+            }
+        }
+    }
+}
+
 // ============================================================================ mean, 5x5 .. 15x15
 // imageMeanBlur, imageTools.cu:313-340, for kernel sizes 5..15 (the reference's wrapper
 // hard-codes 3, :806; its kernel takes any size): integer sums of the k*k flat taps per channel,
@@ -1302,6 +1446,35 @@ static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u3
 }
 
 template <int R>
+static void launch_gauss_wide(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const GaussWide& gw)
+{
+#define MI_L(P) gauss_wide_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+    MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+}
+
+// Weights of gauss_wide_kernel: row weights scaled by 256/65535, column weights as 0.16 fixed point whose sum is
+// exactly 2^16, paired for even steps (w0,w1) .. (w2R,0) and odd steps (0,w0) (w1,w2) ..; false when a weight
+// does not fit 16 bits (a sigma so small that the centre weight rounds to 1: the fp32 kernel takes those).
+static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
+{
+    float w[MI_MAX_KERNEL_SIZE];
+    gaussian_kernel_1d(k, sigma, w);
+    const int R = k / 2;
+    long wc[MI_MAX_KERNEL_SIZE], sum = 0;
+    for (int t = 0; t < k; t++) { wc[t] = lrint((double)w[t] * 65536.0); sum += wc[t]; }
+    wc[R] += 65536 - sum;
+    for (int t = 0; t < k; t++) if (wc[t] < 0 || wc[t] > 65535) return false;
+    for (int t = 0; t < 16; t++) gw->wr[t] = t < k ? (float)((double)w[t] * 256.0 / 65535.0) : 0.f;
+    for (int j = 0; j < 8; j++) {
+        auto at = [&](int t) -> u32 { return (t >= 0 && t < k) ? (u32)wc[t] : 0u; };
+        gw->wc_even[j] = at(2 * j) | (at(2 * j + 1) << 16);
+        gw->wc_odd[j] = at(2 * j - 1) | (at(2 * j) << 16);
+    }
+    return true;
+}
+
+template <int R>
 static void launch_gauss_direct(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const GaussW2& gw)
 {
 #define MI_L(P) gauss_direct_march_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
@@ -1595,9 +1768,17 @@ int launch_filter(const FilterArgs& a)
         case 2: launch_gauss_sep<2>(pol, grid, a.stream, in, out, g, gw); break;
         case 3: launch_gauss_sep<3>(pol, grid, a.stream, in, out, g, gw); break;
         case 4: launch_gauss_sep<4>(pol, grid, a.stream, in, out, g, gw); break;
-        case 5: launch_gauss_sep<5>(pol, grid, a.stream, in, out, g, gw); break;
-        case 6: launch_gauss_sep<6>(pol, grid, a.stream, in, out, g, gw); break;
-        case 7: launch_gauss_sep<7>(pol, grid, a.stream, in, out, g, gw); break;
+        case 5: case 6: case 7: {
+            GaussWide ww;
+            if (tuning().gauss_wide && gauss_wide_weights(a.ksize, a.sigma, &ww)) {
+                if (a.ksize == 11) launch_gauss_wide<5>(pol, grid, a.stream, in, out, g, ww);
+                else if (a.ksize == 13) launch_gauss_wide<6>(pol, grid, a.stream, in, out, g, ww);
+                else launch_gauss_wide<7>(pol, grid, a.stream, in, out, g, ww);
+            } else if (a.ksize == 11) launch_gauss_sep<5>(pol, grid, a.stream, in, out, g, gw);
+            else if (a.ksize == 13) launch_gauss_sep<6>(pol, grid, a.stream, in, out, g, gw);
+            else launch_gauss_sep<7>(pol, grid, a.stream, in, out, g, gw);
+            break;
+        }
         default: return fail(MI_ERR_BAD_KERNEL_SIZE, "separable Gaussian supports kernel sizes 3..15");
         }
         break;

@@ -515,25 +515,26 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
     }
 }
 
-// ============================================================================ Gaussian, separable, 11x11 .. 15x15
+// ============================================================================ Gaussian, separable, 7x7 .. 15x15
 // The kernel above keeps its window of K row-pass results as fp32: K x 12 registers per lane, 180 for
 // 15x15 -- the whole register file at two waves per SIMD, 79 of them spilled to scratch, and the vector
-// ALUs idle half the time (profiles/r02_valu_roofline.md).  Here the window is 16-bit fixed point, two
-// ROWS per register:
-//   * the row pass is the same fp32 sum, with its weights scaled by 256/65535, so that
-//     v_cvt_pknorm_u16_f32 (round(x * 65535), two values per instruction) turns two rows' results into
-//     a pair of 8.8 fixed-point values (h * 256, |error| <= 1/512);
+// ALUs idle half the time (profiles/r02_valu_roofline.md).  Here (kernel sizes 7 to 15; measured against the
+// fp32 kernel on 16 4K frames: 7x7 0.245 -> 0.217 ms, 9x9 0.272 -> 0.230, 13x13 0.420 -> 0.303, 15x15
+// 0.502 -> 0.358) the window is 16-bit fixed point, two ROWS per register:
+//   * the row pass sums 16-bit pairs of adjacent pixels with v_dot2_u32_u16 and 0.16 fixed-point weights
+//     whose sum is exactly 2^16 (the centre weight takes the rounding residue); its result, rounded to
+//     8.8 fixed point (|error| <= 1/512), is what the window keeps;
 //   * arrivals 2j and 2j+1 (rows in marching order) share a register; a step's window is R + 1
 //     consecutive pairs -- (R + 1) x 12 registers, 96 for 15x15 -- whatever the parity of the step:
 //     an even step weights them (w0,w1) (w2,w3) .. (w2R,0), an odd one (0,w0) (w1,w2) .. (w2R-1,w2R);
-//   * the column pass is R + 1 v_dot2_u32_u16 per value with the weights as 0.16 fixed point whose sum is
-//     exactly 2^16 (the centre weight takes the rounding residue): the accumulator is the result in 8.24
-//     fixed point, its top byte the truncated output (imageTools.cu:306-308 truncates too).  Integer
-//     sums do not depend on the order: any decomposition into bands or strips gives the same bytes.
-// Error against the exact real-valued sum: 1/512 from the 8.8 rows + 255 * sum |w_t - wc_t / 2^16|
-// <= 255 * 2K * 2^-17 = 0.06 + the row pass's fp32 rounding (1e-4): < 0.07, far inside the
-// +-1 LSB the separable form is allowed; a constant image comes out exactly constant.
-struct GaussWide { float wr[16]; u32 wc_even[8]; u32 wc_odd[8]; };
+//   * the column pass is R + 1 v_dot2_u32_u16 per value with the same weights: the accumulator is the
+//     result in 8.24 fixed point, its top byte the truncated output (imageTools.cu:306-308 truncates too).
+//     Integer sums do not depend on the order: any decomposition into bands or strips gives the same bytes.
+// Error against the exact real-valued sum: each pass 255 * sum |w_t - wc_t / 2^16| <= 255 * 2K * 2^-17
+// = 0.03, plus 1/512 from the 8.8 rows: < 0.07 in all, far inside the +-1 LSB the separable form is
+// allowed; a constant image comes out exactly constant.  (fp32 multiply-adds cost one issue slot per
+// tap, a 16-bit dot product 0.8, and the byte -> float conversions go away: profiles/r02_valubench.txt.)
+struct GaussWide { u32 wc_even[8]; u32 wc_odd[8]; };
 
 #ifndef MI_GW_WAVES
 #define MI_GW_WAVES 2
@@ -555,8 +556,12 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
         if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
         return r;
     };
-    // row pass, as in gauss_sep_kernel: h[3*q+c] = the two adjacent outputs 2q, 2q+1 of channel c
-    auto hrow = [&](const RowIn& r, f32x2 (&h)[6]) __attribute__((always_inline)) {
+    // Row pass, in integers too: the strip's pixels and their neighbours (columns -8 .. 11) as 16-bit pairs of
+    // horizontally adjacent pixels of one channel (one v_perm_b32 per pair), R + 1 dot products per output
+    // with the same 0.16 weights -- shifted by one for the outputs whose first tap is the second half of a
+    // pair.  h[v], v = 2 * (3 * (k / 2) + c) + k % 2 for pixel k and channel c, is the row sum in 8.16 fixed
+    // point plus 128 (so that cutting it to 8.8 below rounds to nearest).
+    auto irow = [&](const RowIn& r, u32 (&h)[12]) __attribute__((always_inline)) {
         u32 col[20];
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
@@ -572,49 +577,47 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
             col[k] = from_left(col[4 + k], (HOPS > 1 && k >= 4 - N2) ? a2[(k - (4 - N2)) & 3] : 0u);
             col[16 + k] = from_right(col[12 + k], (HOPS > 1 && k < N2) ? a2[k] : 0u);
         }
-        float f[4 + 2 * R][3];
+        constexpr int P0 = (8 - R) / 2, P1 = (11 + R) / 2;      // pairs of columns 2j-8, 2j-7 that some output reads
+        u32 pair[10][3];
 #pragma unroll
-        for (int i = 0; i < 4 + 2 * R; i++) {
-            const u32 v = col[8 - R + i];
-            f[i][0] = (float)(v & 0xffu);
-            f[i][1] = (float)((v >> 8) & 0xffu);
-            f[i][2] = (float)((v >> 16) & 0xffu);
-        }
+        for (int jp = P0; jp <= P1; jp++)
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+            for (int c = 0; c < 3; c++)
+                pair[jp][c] = __builtin_amdgcn_perm(col[2 * jp + 1], col[2 * jp], 0x0c040c00u + (u32)c * 0x00010001u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            constexpr int dummy = 0; (void)dummy;
+            const int ci0 = k - R + 8;                          // the first tap's column, counted from -8
+            const u32* wcr = (ci0 % 2 == 0) ? gw.wc_even : gw.wc_odd;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                f32x2 s = splat2(gw.wr[0]) * f32x2{f[2 * q][c], f[2 * q + 1][c]};
+                u32 a = 128u;
 #pragma unroll
-                for (int t = 1; t < K; t++)
-                    s = __builtin_elementwise_fma(splat2(gw.wr[t]), f32x2{f[2 * q + t][c], f[2 * q + 1 + t][c]}, s);
-                h[3 * q + c] = s;
+                for (int t = 0; t < NP; t++)
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair[ci0 / 2 + t][c]), __builtin_bit_cast(u16x2, wcr[t]), a, false);
+                h[2 * (3 * (k / 2) + c) + (k % 2)] = a;
             }
+        }
     };
-    auto pk = [](float lo, float hi) { return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pknorm_u16(lo, hi)); };
 
-    // win[slot][v]: pair j (arrivals 2j, 2j+1) lives in slot j % NP; v = 2 * (3q + c) + half
+    // win[slot][v]: pair j (arrivals 2j, 2j+1) lives in slot j % NP
     u32 win[NP][12];
-    f32x2 even[6];               // the row-pass result of the last even arrival, until its partner arrives
+    u32 even[12];                // the row sums of the last even arrival, until its partner arrives
 #pragma unroll
-    for (int e = 0; e < 6; e++) even[e] = f32x2{0.f, 0.f};
+    for (int e = 0; e < 12; e++) even[e] = 0u;
     auto arrive = [&](const RowIn& r, int a) __attribute__((always_inline)) {   // a = arrival index (static after unrolling)
-        f32x2 h[6];
-        hrow(r, h);
+        u32 h[12];
+        irow(r, h);
         const int slot = (a / 2) % NP;
         if (a % 2 == 0) {
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
+            for (int e = 0; e < 12; e++) {
                 even[e] = h[e];
-                win[slot][2 * e] = pk(h[e].x, 0.f);
-                win[slot][2 * e + 1] = pk(h[e].y, 0.f);
+                win[slot][e] = __builtin_amdgcn_perm(0u, h[e], 0x0c0c0201u);          // (8.8 of this row, 0)
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 6; e++) {
-                win[slot][2 * e] = pk(even[e].x, h[e].x);
-                win[slot][2 * e + 1] = pk(even[e].y, h[e].y);
-            }
+            for (int e = 0; e < 12; e++) win[slot][e] = __builtin_amdgcn_perm(h[e], even[e], 0x06050201u);   // (even row, odd row)
         }
     };
     // arrivals 0 .. 2R-1 = input rows row(-R) .. row(R-1)
@@ -1453,8 +1456,8 @@ static void launch_gauss_wide(int pol, int grid, hipStream_t s, const u32* in, u
 #undef MI_L
 }
 
-// Weights of gauss_wide_kernel: row weights scaled by 256/65535, column weights as 0.16 fixed point whose sum is
-// exactly 2^16, paired for even steps (w0,w1) .. (w2R,0) and odd steps (0,w0) (w1,w2) ..; false when a weight
+// Weights of gauss_wide_kernel: 0.16 fixed point whose sum is exactly 2^16, paired for an even first tap
+// (w0,w1) .. (w2R,0) and an odd one (0,w0) (w1,w2) ..; false when a weight
 // does not fit 16 bits (a sigma so small that the centre weight rounds to 1: the fp32 kernel takes those).
 static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
 {
@@ -1465,7 +1468,6 @@ static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
     for (int t = 0; t < k; t++) { wc[t] = lrint((double)w[t] * 65536.0); sum += wc[t]; }
     wc[R] += 65536 - sum;
     for (int t = 0; t < k; t++) if (wc[t] < 0 || wc[t] > 65535) return false;
-    for (int t = 0; t < 16; t++) gw->wr[t] = t < k ? (float)((double)w[t] * 256.0 / 65535.0) : 0.f;
     for (int j = 0; j < 8; j++) {
         auto at = [&](int t) -> u32 { return (t >= 0 && t < k) ? (u32)wc[t] : 0u; };
         gw->wc_even[j] = at(2 * j) | (at(2 * j + 1) << 16);
@@ -1766,8 +1768,15 @@ int launch_filter(const FilterArgs& a)
         switch (a.ksize / 2) {
         case 1: launch_gauss_sep<1>(pol, grid, a.stream, in, out, g, gw); break;
         case 2: launch_gauss_sep<2>(pol, grid, a.stream, in, out, g, gw); break;
-        case 3: launch_gauss_sep<3>(pol, grid, a.stream, in, out, g, gw); break;
-        case 4: launch_gauss_sep<4>(pol, grid, a.stream, in, out, g, gw); break;
+        case 3: case 4: {
+            GaussWide ww;
+            if (tuning().gauss_wide && gauss_wide_weights(a.ksize, a.sigma, &ww)) {
+                if (a.ksize == 7) launch_gauss_wide<3>(pol, grid, a.stream, in, out, g, ww);
+                else launch_gauss_wide<4>(pol, grid, a.stream, in, out, g, ww);
+            } else if (a.ksize == 7) launch_gauss_sep<3>(pol, grid, a.stream, in, out, g, gw);
+            else launch_gauss_sep<4>(pol, grid, a.stream, in, out, g, gw);
+            break;
+        }
         case 5: case 6: case 7: {
             GaussWide ww;
             if (tuning().gauss_wide && gauss_wide_weights(a.ksize, a.sigma, &ww)) {

@@ -28,7 +28,7 @@ struct Tuning {
     int fft_split = 1;            // MI_FFT_SPLIT
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
-    int gauss_wide = 1;           // MI_GAUSS_WIDE: 11x11..15x15 separable Gaussians with the 16-bit fixed-point column pass
+    int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
     int fft_col_tile = 1;         // MI_FFT_COL_TILE: single-pass column transform of tall planes in LDS tiles
 };
 const Tuning& tuning();

@@ -540,3 +540,28 @@ def test_very_wide_image_leaves_the_32bit_offset_path(dev, golden):
     assert np.array_equal(ops.sobel(d).cpu().numpy(), golden.sobel(img))
     assert np.array_equal(ops.mean_blur(d, 3).cpu().numpy(), golden.meanblur(img, 3))
 
+
+@pytest.mark.parametrize("k", [7, 9, 11, 13, 15])
+def test_fixed_point_gaussian_stays_within_one_level(dev, golden, k):
+    """Separable Gaussians of 7x7..15x15 run in 16-bit fixed point (gauss_wide_kernel; error bound < 0.07 before
+    the truncating store): within 1 level of the oracle's direct fp32 sum for narrow, usual and very wide sigmas,
+    on noise (every tap matters) and on a smooth image (values sit near integers, where truncation flips);
+    a constant image comes out exactly constant; a sigma so small that a weight would not fit 16 bits takes
+    the fp32 kernel, same bar."""
+    w, h = 516, 75
+    imgs = [S.synth_image(k, w, h), S.pattern_image("natural", w, h, k)]
+    for sigma in (0.05, 0.7, 2.5, 10.0):
+        for img in imgs:
+            want = golden.gaussian(img, k, sigma).astype(np.int16)
+            d = torch.from_numpy(img).to(dev)
+            got = ops.gaussian_blur(d, k, sigma).cpu().numpy().astype(np.int16)
+            assert np.abs(got - want).max() <= GAUSS_TOL, (k, sigma)
+            with ops.tuning(MI_GAUSS_WIDE=0, restore={"MI_GAUSS_WIDE": 1}):
+                fp32 = ops.gaussian_blur(d, k, sigma).cpu().numpy().astype(np.int16)
+            assert np.abs(fp32 - want).max() <= GAUSS_TOL, (k, sigma)
+    r = k // 2
+    for v in (0, 1, 77, 128, 254, 255):
+        const = torch.full((h, w, 4), v, dtype=torch.uint8, device=dev)
+        out = ops.gaussian_blur(const, k, 2.0)
+        assert int(out[r + 1:h - r - 1, r:w - r, :3].min()) == v and int(out[r + 1:h - r - 1, r:w - r, :3].max()) == v
+

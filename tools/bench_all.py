@@ -97,17 +97,17 @@ report(f"fft2d forward ({C5})", "cufftExecC2C :690-701", pxf, 32, lambda: ops.ff
 report(f"fft2d inverse ({C5})", "cufftExecC2C :741-751", pxf, 32, lambda: ops.fft2d(f, inverse=True, out=y), 10)
 report(f"fft2d forward + inverse ({C5})", "C5 round trip", pxf, 64, lambda: (ops.fft2d(x, out=f), ops.fft2d(f, inverse=True, out=y)), 10)
 one = x[0]
-report("fftShift (4096x4096)", ":564-583", n * n, 16, lambda: ops.fftshift_(one), 20, "one plane: fits the Infinity Cache")
-report("highpassFilter (4096x4096)", ":530-549", n * n, 16, lambda: ops.highpass_(one, 10.0), 20, "one plane")
-report("NormalizeAndZeroImaginary (4096x4096)", ":551-562", n * n, 16, lambda: ops.normalize_zero_imag_(one), 20, "one plane")
+report("fftShift (4096x4096)", ":564-583", n * n, 16, lambda: ops.fftshift_(one), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
+report("highpassFilter (4096x4096)", ":530-549", n * n, 16, lambda: ops.highpass_(one, 10.0), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
+report("NormalizeAndZeroImaginary (4096x4096)", ":551-562", n * n, 16, lambda: ops.normalize_zero_imag_(one), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 img = ops.synth(5, n, n)
-report("uchar4ToCufftComplex (4096x4096)", ":506-515", n * n, 28, lambda: ops.u8_to_complex(img), 20, "allocates its 3 planes per call")
+report("uchar4ToCufftComplex (4096x4096)", ":506-515", n * n, 28, lambda: ops.u8_to_complex(img), 20, "allocates its 3 planes per call; Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 pl = ops.u8_to_complex(img)
-report("ComplexRGBToUchar (4096x4096)", ":517-527", n * n, 28, lambda: ops.complex_to_u8(pl[0], pl[1], pl[2]), 20)
+report("ComplexRGBToUchar (4096x4096)", ":517-527", n * n, 28, lambda: ops.complex_to_u8(pl[0], pl[1], pl[2]), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 fl = x[0].real.contiguous()
-report("findMinMax (4096x4096)", ":416-454", n * n, 4, lambda: ops.minmax(fl), 20)
+report("findMinMax (4096x4096)", ":416-454", n * n, 4, lambda: ops.minmax(fl), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 mm = ops.minmax(fl)
-report("floatToUchar4 normalise (4096x4096)", ":458-471", n * n, 8, lambda: ops.normalize_to_u8(fl, mm), 20)
+report("floatToUchar4 normalise (4096x4096)", ":458-471", n * n, 8, lambda: ops.normalize_to_u8(fl, mm), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 # non power of two: the reference's demo image size and the sample image size
 for (r, c) in ((900, 675), (2000, 2592)):
     z = torch.complex(torch.rand(r, c, device="cuda"), torch.rand(r, c, device="cuda"))

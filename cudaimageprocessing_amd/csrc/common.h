@@ -314,30 +314,42 @@ struct RowIO<1> {
 // issued, so s_waitcnt vmcnt(K + L) -- vmcnt(L) while fewer than K stores can lie in between --
 // means "the rows of the next K steps have landed".  Waiting for more than necessary is always safe.
 //
-// HALO1: each row also carries the one pixel next to the strip on either side (3x3 filters), a dword
-// per edge lane in a second, 256-byte part of the ring slot.
+// HALO: what a row carries beside the strip's own pixels, in a second, 256-byte part of the ring slot,
+// fetched by ONE more 4-byte-per-lane request: 1 = the one pixel next to the strip on either side
+// (3x3 filters; a dword in each edge lane), 4 or 8 = the one or two 4-pixel groups on either side
+// (lanes 0..HALO-1 fetch the left pixels, lanes HALO..2*HALO-1 the right ones; Row::near and Row::far
+// then hold, in lane 0, the nearer and the farther group to the left, in lane 63 those to the right).
 // Usage: feed.start(first_row_index) once, then feed.next(c, prime) for consumption c = 0, 1, 2, ...
 // (rows first, first+1, ... in marching order); `prime` = consumptions before the kernel's first store.
 // For POL 0 the feed degenerates to the one-row-ahead register prefetch.
-template <int POL, int K_, bool HALO1>
+template <int POL, int K_, int HALO>
 struct RowFeed {
+    static constexpr bool HALO1 = HALO != 0;
     static constexpr bool LDSQ = POL == 1 && K_ > 0;   // K_ = 0: the register prefetch for every policy
     static constexpr int K = K_ > 0 ? K_ : 1;
     static constexpr int SLOT_BYTES = HALO1 ? 1280 : 1024;
     static constexpr int WAVE_BYTES = 2 * K * SLOT_BYTES;
     static constexpr int BLOCK_BYTES = LDSQ ? 4 * WAVE_BYTES : 16;    // the __shared__ ring a 256-lane block declares
     static constexpr int L = HALO1 ? 2 * K : K;           // loads per burst
-    struct Row { u32x4 p; u32 h; };
+    struct Row { u32x4 p; u32 h; u32x4 near, far; };
 
     const RowIO<POL>& io;
     const March& mch;
     unsigned char* ring;       // this wave's 2K slots
     int first, lane;
     int phase = 0, slot = 0;
+    int group_off = 0;         // HALO >= 4: this lane's pixel of the halo groups (out of range for lanes >= 2 * HALO)
     Row nxt{};                 // POL 0 only
 
     MI_DEV RowFeed(const RowIO<POL>& io_, const March& m_, unsigned char* block_ring, int lane_)
-        : io(io_), mch(m_), ring(block_ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * WAVE_BYTES), first(0), lane(lane_) {}
+        : io(io_), mch(m_), ring(block_ring + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * WAVE_BYTES), first(0), lane(lane_)
+    {
+        if constexpr (LDSQ && HALO >= 4) {
+            const int base0 = io.in_off - 16 * lane_;        // lane 0's pixels
+            group_off = lane_ < HALO ? base0 - 4 * HALO + 4 * lane_
+                                     : (lane_ < 2 * HALO ? base0 + 1024 + 4 * (lane_ - HALO) : (int)0x80000000);
+        }
+    }
 
     MI_DEV void request(int row, int s)
     {
@@ -345,9 +357,12 @@ struct RowFeed {
         if constexpr (LDSQ) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(ring + s * SLOT_BYTES), 16,
                                                      (row - io.row0) * io.pitch + io.in_off, 0, 0, 0);
-            if constexpr (HALO1)
+            if constexpr (HALO == 1)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(ring + s * SLOT_BYTES + 1024), 4,
                                                          (row - io.row0) * io.pitch + io.halo1_off, 0, 0, 0);
+            if constexpr (HALO >= 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(io.rin, (__attribute__((address_space(3))) void*)(ring + s * SLOT_BYTES + 1024), 4,
+                                                         (row - io.row0) * io.pitch + group_off, 0, 0, 0);
         }
 #endif
     }
@@ -360,9 +375,11 @@ struct RowFeed {
     }
     MI_DEV Row load_direct(int row) const
     {
-        Row r;
+        Row r{};
         r.p = io.load(row);
-        r.h = HALO1 ? io.load_halo1(row) : 0u;
+        if constexpr (HALO == 1) r.h = io.load_halo1(row);
+        if constexpr (HALO >= 4) r.near = io.load_halo(row, 1);
+        if constexpr (HALO >= 8) r.far = io.load_halo(row, 2);
         return r;
     }
     // requests rows first .. first+K-1 (marching order)
@@ -379,7 +396,7 @@ struct RowFeed {
     // the row of consumption c (= row index first + c); c must count 0, 1, 2, ...
     MI_DEV Row next(int c, int prime)
     {
-        Row r;
+        Row r{};
         if constexpr (LDSQ) {
             if (phase == 0) {
                 const int half = slot >= K ? 0 : K;      // the half of the ring the last K consumptions have read
@@ -389,7 +406,13 @@ struct RowFeed {
             }
             const unsigned char* sl = ring + slot * SLOT_BYTES;
             r.p = *reinterpret_cast<const u32x4*>(sl + 16 * lane);
-            r.h = HALO1 ? *reinterpret_cast<const u32*>(sl + 1024 + 4 * lane) : 0u;
+            r.h = HALO == 1 ? *reinterpret_cast<const u32*>(sl + 1024 + 4 * lane) : 0u;
+            if constexpr (HALO >= 4) {
+                // left pixels at bytes [0, 4 HALO), right ones at [4 HALO, 8 HALO); only lanes 0 and 63 use theirs
+                const bool left = lane == 0;
+                r.near = *reinterpret_cast<const u32x4*>(sl + 1024 + (left ? 4 * HALO - 16 : 4 * HALO));
+                if constexpr (HALO >= 8) r.far = *reinterpret_cast<const u32x4*>(sl + 1024 + (left ? 0 : 4 * HALO + 16));
+            }
             phase = phase + 1 == K ? 0 : phase + 1;
             slot = slot + 1 == 2 * K ? 0 : slot + 1;
         } else {

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void sobel_kernel(const u32* __restrict__ in,
     u32 t01, t23, m01, m23, b01, b23, th, mh, bh;
     // t = oldest row of the window, b = newest.  Marching up swaps their roles, which only flips
     // the sign of Gy; Gx^2 + Gy^2 does not change.
-    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    typedef RowFeed<POL, MI_FEED_K, 1> Feed;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     Feed feed(io, mch, ring, j.lane);
     feed.start(-1);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void mean3_kernel(const u32* __restrict__ in,
     };
 
     u32 tl[4], th[4], ml[4], mh[4], bl[4], bh[4];
-    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    typedef RowFeed<POL, MI_FEED_K, 1> Feed;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     Feed feed(io, mch, ring, j.lane);
     feed.start(-1);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void median3_kernel(const u32* __restrict__ in
     };
 
     u32 win[3][8];
-    typedef RowFeed<POL, MI_FEED_K, true> Feed;
+    typedef RowFeed<POL, MI_FEED_K, 1> Feed;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     Feed feed(io, mch, ring, j.lane);
     feed.start(-1);
@@ -539,6 +539,9 @@ struct GaussWide { u32 wc_even[8]; u32 wc_odd[8]; };
 #ifndef MI_GW_WAVES
 #define MI_GW_WAVES 2
 #endif
+#ifndef MI_GW_BURST
+#define MI_GW_BURST 4     // rows per request burst (RowFeed); 0: one row ahead, in registers
+#endif
 template <int R, int POL>
 __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32* __restrict__ in, u32* __restrict__ out,
                                                             const Geo g, const GaussWide gw)
@@ -548,14 +551,13 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
     constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;
     MI_MARCH_PROLOGUE();
 
-    struct RowIn { u32x4 p, h1, h2; };
-    auto load_row = [&](int row) __attribute__((always_inline)) {
-        RowIn r;
-        r.p = io.load(row);
-        r.h1 = io.template load_halo_px<N1>(row, 1);
-        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
-        return r;
-    };
+    // input rows in bursts through a per-wave LDS ring (RowFeed, common.h), with the one or two 4-pixel groups
+    // beside the strip; a1 / a2 below: element i = the nearer / farther group's pixel 4-N+i in lane 0, i in lane 63
+    typedef RowFeed<POL, MI_GW_BURST, 4 * HOPS> Feed;
+    typedef typename Feed::Row RowIn;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    const bool first_lane = j.lane == 0;
     // Row pass, in integers too: the strip's pixels and their neighbours (columns -8 .. 11) as 16-bit pairs of
     // horizontally adjacent pixels of one channel (one v_perm_b32 per pair), R + 1 dot products per output
     // with the same 0.16 weights -- shifted by one for the outputs whose first tap is the second half of a
@@ -564,8 +566,14 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
     auto irow = [&](const RowIn& r, u32 (&h)[12]) __attribute__((always_inline)) {
         u32 col[20];
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
-        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
-        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+        const u32 n4[4] = {r.near.x, r.near.y, r.near.z, r.near.w}, f4[4] = {r.far.x, r.far.y, r.far.z, r.far.w};
+        u32 a1[4] = {0u, 0u, 0u, 0u}, a2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < N1; i++) a1[i] = first_lane ? n4[4 - N1 + i] : n4[i];
+        if constexpr (HOPS > 1) {
+#pragma unroll
+            for (int i = 0; i < N2; i++) a2[i] = first_lane ? f4[4 - N2 + i] : f4[i];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             col[8 + k] = p[k];
@@ -620,10 +628,10 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
             for (int e = 0; e < 12; e++) win[slot][e] = __builtin_amdgcn_perm(h[e], even[e], 0x06050201u);   // (even row, odd row)
         }
     };
-    // arrivals 0 .. 2R-1 = input rows row(-R) .. row(R-1)
+    // arrivals 0 .. 2R-1 = input rows row(-R) .. row(R-1); the first store follows arrival 2R
+    feed.start(-R);
 #pragma unroll
-    for (int a = 0; a < 2 * R; a++) arrive(load_row(mch.row(a - R)), a);
-    RowIn nxt = load_row(mch.row(R));
+    for (int a = 0; a < 2 * R; a++) arrive(feed.next(a, 2 * R), a);
 
     constexpr int UNR = 2 * NP;      // pair slots and parities repeat with this period
     for (int base = 0; base < mch.n; base += UNR) {
@@ -633,8 +641,7 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
             if (i < mch.n) {
             const int y = mch.row(i);
             // arrival i + 2R (2R is even: its parity and, up to a constant, its slot are those of s)
-            arrive(nxt, s + 2 * R);
-            nxt = load_row(mch.row(i + R + 1));
+            arrive(feed.next(i + 2 * R, 2 * R), s + 2 * R);
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             // the window: pairs first .. first + R, first = floor(s / 2) (+ R * k, which the ring hides)
             const u32* wc = (s % 2 == 0) ? gw.wc_even : gw.wc_odd;
@@ -890,7 +897,7 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
                                                     u32* __restrict__ out, const Geo g,
                                                     const GaussW gw)
 {
-    typedef RowFeed<POL, MI_CHAIN_BURST, false> Feed;
+    typedef RowFeed<POL, MI_CHAIN_BURST, 0> Feed;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     const WaveJob j = wave_job(g);
     if (!j.valid) return;

@@ -17,7 +17,10 @@ F = {
     "median3": lambda: ops.median_blur(frames, 3, out),
     "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
     "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),
+    "gauss7": lambda: ops.gaussian_blur(frames, 7, 1.5, out),
     "gauss9": lambda: ops.gaussian_blur(frames, 9, 2.0, out),
+    "gauss11": lambda: ops.gaussian_blur(frames, 11, 2.0, out),
+    "gauss13": lambda: ops.gaussian_blur(frames, 13, 2.2, out),
     "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
     "mean7": lambda: ops.mean_blur(frames, 7, out),
     "mean15": lambda: ops.mean_blur(frames, 15, out),

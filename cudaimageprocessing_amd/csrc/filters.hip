@@ -89,6 +89,9 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
     r23 = __builtin_amdgcn_perm(p.w, p.z, 0x0c040c00u);
 }
 
+#ifndef MI_SEP_BURST
+#define MI_SEP_BURST 3    // rows per request burst of the separable Gaussian (fp32) and mean kernels; 0: one row ahead, in registers
+#endif
 #ifndef MI_FEED_K
 #define MI_FEED_K 0       // rows per request burst of the 3x3 march kernels (RowFeed in common.h); 0: one row ahead, in registers
                           // (measured: with their 6-row bands bursts of 2 change nothing, bursts of 3 or 4 cost 3..5 %)
@@ -408,14 +411,13 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
     constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;   // pixels used of halo groups 1 and 2
     MI_MARCH_PROLOGUE();
 
-    struct RowIn { u32x4 p, h1, h2; };
-    auto load_row = [&](int row) {
-        RowIn r;
-        r.p = io.load(row);
-        r.h1 = io.template load_halo_px<N1>(row, 1);
-        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
-        return r;
-    };
+    // input rows in bursts through a per-wave LDS ring (RowFeed, common.h) with the 4-pixel groups beside the strip
+    // (3x3: 6-row bands, where bursts gain nothing and the ring would cap the occupancy: one row ahead, in registers)
+    typedef RowFeed<POL, (R == 1 ? 0 : MI_SEP_BURST), 4 * HOPS> Feed;
+    typedef typename Feed::Row RowIn;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    const bool first_lane = j.lane == 0;
 
     // Row pass: h[3*p+c] = sum_t w[t] * channel c of columns (2p - R + t, 2p + 1 - R + t), p = 0,1:
     // two adjacent output pixels per packed fp32 operation (v_pk_mul_f32 / v_pk_fma_f32, each
@@ -425,8 +427,14 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         // halo group pixels: element i is the group's pixel 4-N+i in lane 0 (left of the strip) and
         // its pixel i in lane 63 (right of it); the shifts only read those two lanes' edge values
-        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
-        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+        const u32 n4[4] = {r.near.x, r.near.y, r.near.z, r.near.w}, f4[4] = {r.far.x, r.far.y, r.far.z, r.far.w};
+        u32 a1[4] = {0u, 0u, 0u, 0u}, a2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < N1; i++) a1[i] = first_lane ? n4[4 - N1 + i] : n4[i];
+        if constexpr (HOPS > 1) {
+#pragma unroll
+            for (int i = 0; i < N2; i++) a2[i] = first_lane ? f4[4 - N2 + i] : f4[i];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             col[8 + k] = p[k];
@@ -460,36 +468,20 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 
     f32x2 win[K][6];
     // input rows row(-R) .. row(R-1) fill slots 0 .. K-2 (the weights are symmetric, so the
-    // marching direction does not matter to the column pass)
+    // marching direction does not matter to the column pass); the first store follows row(R)
+    feed.start(-R);
 #pragma unroll
     for (int i = 0; i < K - 1; i++)
-        hrow(load_row(mch.row(i - R)), win[i]);
-    // DEEP (9x9): two rows in flight, in three register sets that rotate with the step -- the loop is
-    // unrolled by K = 9, a multiple of 3, so the set index is static and no row is ever copied.  Measured:
-    // 308 -> 264 us; no gain for 3x3..7x7 (memory- or VALU-bound, and 5x5 / 7x7 would need 3K steps unrolled).
-    constexpr bool DEEP = R == 4;              // (15x15, also a multiple of 3, has no registers for a third row: 2.5x slower)
+        hrow(feed.next(i, K - 1), win[i]);
     constexpr int UNR = K;
-    RowIn pf[3];
-    RowIn nxt = load_row(mch.row(R));
-    if constexpr (DEEP) { pf[0] = nxt; pf[1] = load_row(mch.row(R + 1)); }
-
     for (int base = 0; base < mch.n; base += UNR) {
 #pragma unroll
         for (int s = 0; s < UNR; s++) {
             const int i = base + s;
-            // the next row is requested on every step, valid or not (a load beyond the band is harmless):
-            // assigned unconditionally, `nxt` needs no merge at the end of the guarded block below, and
-            // so no register copy that would make the wave wait for the load it has just issued
-            // (only where registers allow both rows to be live: the wide kernels keep the load in the block)
-            constexpr bool EAGER = R <= 4 && !DEEP;
-            if constexpr (DEEP) pf[(s + 2) % 3] = load_row(mch.row(i + R + 2));
-            const RowIn cur = DEEP ? pf[s % 3] : nxt;
-            if constexpr (EAGER) nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // newest input row y+R goes to slot (K-1+s)%K; tap t of the column pass is slot (s+t)%K
-            hrow(cur, win[(K - 1 + s) % K]);
-            if constexpr (!EAGER && !DEEP) nxt = load_row(mch.row(i + R + 1));
+            hrow(feed.next(i + K - 1, K - 1), win[(K - 1 + s) % K]);
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -540,7 +532,7 @@ struct GaussWide { u32 wc_even[8]; u32 wc_odd[8]; };
 #define MI_GW_WAVES 2
 #endif
 #ifndef MI_GW_BURST
-#define MI_GW_BURST 4     // rows per request burst (RowFeed); 0: one row ahead, in registers
+#define MI_GW_BURST 3     // rows per request burst (RowFeed; 2, 3 and 4 measure the same, 6 and 8 cost 1..8 %); 0: one row ahead, in registers
 #endif
 template <int R, int POL>
 __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32* __restrict__ in, u32* __restrict__ out,
@@ -693,22 +685,26 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
     constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;   // pixels used of halo groups 1 and 2
     MI_MARCH_PROLOGUE();
 
-    struct RowIn { u32x4 p, h1, h2; };
-    auto load_row = [&](int row) {
-        RowIn r;
-        r.p = io.load(row);
-        r.h1 = io.template load_halo_px<N1>(row, 1);
-        if constexpr (HOPS > 1) r.h2 = io.template load_halo_px<N2>(row, 2); else r.h2 = u32x4{0u, 0u, 0u, 0u};
-        return r;
-    };
+    // input rows in bursts through a per-wave LDS ring (RowFeed, common.h) with the 4-pixel groups beside the strip
+    typedef RowFeed<POL, MI_SEP_BURST, 4 * HOPS> Feed;
+    typedef typename Feed::Row RowIn;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    const bool first_lane = j.lane == 0;
     // h[2k] = (R,B) sums, h[2k+1] = (G,A) sums over columns k-R .. k+R, for the lane's pixel k
     auto hrow = [&](const RowIn& r, u32 (&h)[8]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         // halo group pixels: element i is the group's pixel 4-N+i in lane 0 (left of the strip) and
         // its pixel i in lane 63 (right of it); the shifts only read those two lanes' edge values
-        const u32 a1[4] = {r.h1.x, r.h1.y, r.h1.z, r.h1.w};
-        const u32 a2[4] = {r.h2.x, r.h2.y, r.h2.z, r.h2.w};
+        const u32 n4[4] = {r.near.x, r.near.y, r.near.z, r.near.w}, f4[4] = {r.far.x, r.far.y, r.far.z, r.far.w};
+        u32 a1[4] = {0u, 0u, 0u, 0u}, a2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < N1; i++) a1[i] = first_lane ? n4[4 - N1 + i] : n4[i];
+        if constexpr (HOPS > 1) {
+#pragma unroll
+            for (int i = 0; i < N2; i++) a2[i] = first_lane ? f4[4 - N2 + i] : f4[i];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             col[8 + k] = p[k];
@@ -737,29 +733,22 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
 
     u32 win[K][8];
     u32 cs[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    feed.start(-R);
 #pragma unroll
     for (int i = 0; i < K - 1; i++) {
-        hrow(load_row(mch.row(i - R)), win[i]);
+        hrow(feed.next(i, K - 1), win[i]);
 #pragma unroll
         for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[i][e]);
     }
-    // (see gauss_sep_kernel: the next row is requested unconditionally; 9x9 keeps two rows in flight)
-    constexpr bool DEEP = R >= 3 && R != 6;   // 13x13 would unroll 39 steps: measured 2.6x slower (instruction cache)
-    constexpr int UNR = DEEP && K % 3 != 0 ? 3 * K : K;   // a multiple of K (window slots) and of 3 (row sets)
-    RowIn pf[3];
-    RowIn nxt = load_row(mch.row(R));
-    if constexpr (DEEP) { pf[0] = nxt; pf[1] = load_row(mch.row(R + 1)); }
+    constexpr int UNR = K;
     for (int base = 0; base < mch.n; base += UNR) {
 #pragma unroll
         for (int s = 0; s < UNR; s++) {
             const int i = base + s;
-            if constexpr (DEEP) pf[(s + 2) % 3] = load_row(mch.row(i + R + 2));
-            const RowIn cur = DEEP ? pf[s % 3] : nxt;
-            if constexpr (!DEEP) nxt = load_row(mch.row(i + R + 1));
             if (i < mch.n) {
             const int y = mch.row(i);
             // rows y-R+t live in slot (s+t)%K; the newest one, y+R, replaces the row dropped last step
-            hrow(cur, win[(K - 1 + s) % K]);
+            hrow(feed.next(i + K - 1, K - 1), win[(K - 1 + s) % K]);
 #pragma unroll
             for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[(K - 1 + s) % K][e]);
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;

@@ -22,7 +22,9 @@ F = {
     "gauss11": lambda: ops.gaussian_blur(frames, 11, 2.0, out),
     "gauss13": lambda: ops.gaussian_blur(frames, 13, 2.2, out),
     "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
+    "mean5": lambda: ops.mean_blur(frames, 5, out),
     "mean7": lambda: ops.mean_blur(frames, 7, out),
+    "mean11": lambda: ops.mean_blur(frames, 11, out),
     "mean15": lambda: ops.mean_blur(frames, 15, out),
     "median5": lambda: ops.median_blur(frames, 5, out),
     "chain": lambda: ops.fused_chain(frames, 1.0, out),

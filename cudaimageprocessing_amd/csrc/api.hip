@@ -363,8 +363,9 @@ int mi_fft2d_c2c_f32_dev(const void* d_in, void* d_out, int rows, int cols, int 
     if (!d_in || !d_out) return fail(MI_ERR_INVALID_ARG, "null pointer");
     if (batch <= 0) return fail(MI_ERR_INVALID_ARG, "non-positive batch");
     if (direction != MI_FFT_FORWARD && direction != MI_FFT_INVERSE) return fail(MI_ERR_INVALID_ARG, "direction must be -1 or +1");
-    auto pow2 = [](int n) { return n >= 2 && n <= 8192 && (n & (n - 1)) == 0; };
-    if (!pow2(rows) || !pow2(cols)) return fail(MI_ERR_UNSUPPORTED, "fft2d needs power-of-two sizes in [2,8192] (got %dx%d)", rows, cols);
+    auto pow2 = [](int n) { return n >= 2 && (n & (n - 1)) == 0; };
+    if (!pow2(rows) || !pow2(cols) || !fft2d_size_supported(rows, cols))
+        return fail(MI_ERR_UNSUPPORTED, "fft2d needs power-of-two sizes in [2,%d] and fewer than 2^28 points a plane (got %dx%d)", MI_FFT_MAX_POW2, rows, cols);
     const size_t bytes = (size_t)rows * cols * 8 * batch;
     if (d_in != d_out && overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping buffers");
     return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream);
@@ -374,7 +375,8 @@ int mi_fft2d_workspace_bytes(int rows, int cols, size_t* bytes)
 {
     if (!bytes) return fail(MI_ERR_INVALID_ARG, "null pointer");
     if (!fft2d_size_supported(rows, cols))
-        return fail(MI_ERR_UNSUPPORTED, "fft2d sizes must be in [2,4096] or a power of two up to 8192 (got %dx%d)", rows, cols);
+        return fail(MI_ERR_UNSUPPORTED, "fft2d sizes must be in [2,%d] or a power of two up to %d, fewer than 2^28 points a plane (got %dx%d)",
+                    MI_FFT_MAX_ANY, MI_FFT_MAX_POW2, rows, cols);
     *bytes = fft2d_workspace_bytes(rows, cols);
     return MI_OK;
 }

@@ -27,8 +27,8 @@ MI_DEV c2 csub(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
 MI_DEV c2 cmul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 MI_DEV c2 mul_neg_i(c2 a) { return c2{a.y, -a.x}; }   // a * (-i)
 
-constexpr int TW_N = 8192;
-__device__ c2 g_twiddle[TW_N];   // exp(-2*pi*i*n/8192)
+constexpr int TW_N = 16384;
+__device__ c2 g_twiddle[TW_N];   // exp(-2*pi*i*n/16384)
 
 __global__ void twiddle_init_kernel()
 {
@@ -111,7 +111,7 @@ MI_DEV void dft<16>(c2 (&x)[16])
 // q = (plane, g) with g = q % groups.  Its points sit at
 //   in :  plane*plane_stride + g*in_group_stride  + c*line_stride + i*in_elem_stride
 //   out:  plane*plane_stride + g*out_group_stride + c*line_stride + k*out_elem_stride
-// and, when tw_step != 0, output k is multiplied by exp(-2 pi i * g*k*tw_step / 8192) (the
+// and, when tw_step != 0, output k is multiplied by exp(-2 pi i * g*k*tw_step / 16384) (the
 // twiddle between the two halves of a split column transform).
 //   row pass:        inner = 1 line per "c", groups = rows: g*cols, elem stride 1
 //   column pass:     inner = cols, groups = 1, elem stride cols
@@ -152,6 +152,8 @@ MI_DEV int lds_pad(int i) { return i + (i >> 4); }   // one spare slot per 16: b
 // table [(q-1) * NS + ktw] = exp(-2 pi i q ktw / (NS R)), q = 1..R-1, ktw = 0..NS-1, filled once
 // per block: inside the line loop the only vector-memory traffic is then the lines themselves, so
 // the in-order vmcnt counter never makes a stage wait for the prefetch of the next line.
+// A 16384-point line fills 136 KiB of LDS by itself: only its first table (240 entries) joins it
+// there, the later stages read the device table (L2 hits; such blocks do not prefetch).
 template <int N>
 struct Plan {
     static constexpr int L = __builtin_ctz(N);
@@ -161,12 +163,13 @@ struct Plan {
     static constexpr int radix(int s) { return s < A ? 16 : REM; }
     static constexpr int ns(int s) { int p = 1; for (int i = 0; i < s; i++) p *= radix(i); return p; }
     static constexpr int tw_off(int s) { int o = 0; for (int i = 1; i < s; i++) o += (radix(i) - 1) * ns(i); return o; }
-    static constexpr int tw_total = tw_off(n_stages);
+    static constexpr int lds_tw_stages = N > 8192 ? 2 : n_stages;   // stages 1..lds_tw_stages-1 have their table in LDS
+    static constexpr int tw_total = tw_off(lds_tw_stages);
 };
 
 // One Stockham stage of radix R over this lane's 16 points (N/16 lanes per line).
 // NS = product of the radices of the earlier stages; tws = this stage's twiddle table.
-template <int N, int R, int NS, bool LAST>
+template <int N, int R, int NS, bool LAST, bool TW_LDS>
 MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, const c2* __restrict__ tws, int t)
 {
     constexpr int T = N / 16, G = 16 / R;
@@ -179,7 +182,7 @@ MI_DEV void fft_stage(c2 (&v)[16], c2* __restrict__ line, const c2* __restrict__
         for (int q = 0; q < R; q++) x[q] = v[m + q * G];
         if (NS > 1) {
 #pragma unroll
-            for (int q = 1; q < R; q++) x[q] = cmul(x[q], tws[(q - 1) * NS + ktw]);
+            for (int q = 1; q < R; q++) x[q] = cmul(x[q], TW_LDS ? tws[(q - 1) * NS + ktw] : g_twiddle[q * ktw * (TW_N / (NS * R))]);
         }
         dft<R>(x);
         if (LAST) {
@@ -204,7 +207,7 @@ MI_DEV void fft_line(c2 (&v)[16], c2* __restrict__ line, const c2* __restrict__ 
 {
     using P = Plan<N>;
     if constexpr (S < P::n_stages) {
-        fft_stage<N, P::radix(S), P::ns(S), S == P::n_stages - 1>(v, line, tw + P::tw_off(S), t);
+        fft_stage<N, P::radix(S), P::ns(S), S == P::n_stages - 1, (S < P::lds_tw_stages)>(v, line, tw + (S < P::lds_tw_stages ? P::tw_off(S) : 0), t);
         fft_line<N, S + 1>(v, line, tw, t);
     }
 }
@@ -214,7 +217,7 @@ template <int N, int S = 1>
 MI_DEV void fill_twiddles(c2* __restrict__ tw, int tid, int nthreads)
 {
     using P = Plan<N>;
-    if constexpr (S < P::n_stages) {
+    if constexpr (S < P::lds_tw_stages) {
         constexpr int R = P::radix(S), NS = P::ns(S), step = TW_N / (NS * R);
         for (int idx = tid; idx < (R - 1) * NS; idx += nthreads) {
             const int q = idx / NS + 1, k = idx % NS;
@@ -266,7 +269,7 @@ void fft_lines_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Fft
     };
 
     // Inter-pass twiddles of a split column transform: output kk of a line of group gi is
-    // multiplied by exp(-2 pi i gi kk tw_step / 8192).  When all lines of a block iteration share
+    // multiplied by exp(-2 pi i gi kk tw_step / 16384).  When all lines of a block iteration share
     // gi (cols >= LPB: the usual case) the N factors go through a double-buffered LDS table that
     // lanes tid < N fill one iteration ahead -- their single load is issued before the prefetch
     // of that iteration's lines, so nothing in the loop waits for anything younger than itself.
@@ -460,7 +463,7 @@ template <int N, int LPB, bool COL>
 static int launch_lines(const c2* in, c2* out, const FftGeo& g, u32 bytes, hipStream_t s)
 {
     // the inter-pass twiddle is only ever applied by the short column transforms of a split pass
-    if constexpr (COL && N <= 128) {
+    if constexpr (COL && N <= 256) {     // R1 = rows / 64 <= 256
         if (g.tw_step) return launch_lines_tw<N, LPB, COL, true>(in, out, g, bytes, s);
     }
     return launch_lines_tw<N, LPB, COL, false>(in, out, g, bytes, s);
@@ -494,6 +497,7 @@ static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, u32 bytes,
     case 2048: return launch_lines<2048, COL ? 8 : 2, COL>(in, out, g, bytes, s);
     case 4096: return launch_lines<4096, COL ? 2 : 1, COL>(in, out, g, bytes, s);   // 2 lines + 32 KiB of twiddles
     case 8192: return launch_lines<8192, 1, COL>(in, out, g, bytes, s);              // 1 line + 64 KiB of twiddles
+    case 16384: return launch_lines<16384, 1, COL>(in, out, g, bytes, s);            // 1 line of 136 KiB
     default: return fail(MI_ERR_UNSUPPORTED, "fft line length %d", n);
     }
 }
@@ -804,6 +808,7 @@ static int any_lines(const c2* src, i64 src_stride, c2* dst, i64 dst_stride, int
         case 2048: return launch_blue_lines<2048, 2>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
         case 4096: return launch_blue_lines<4096, 1>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
         case 8192: return launch_blue_lines<8192, 1>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
+        case 16384: return launch_blue_lines<16384, 1>(src, src_stride, dst, dst_stride, nlines, n, inverse, t, s);
         default: break;    // m = 8 (n = 3): the separate kernels below
         }
     }
@@ -839,8 +844,9 @@ static BlueLayout blue_layout(int rows, int cols)
 
 int fft2d_size_supported(int rows, int cols)
 {
-    auto ok = [](int n) { return n >= 2 && (n <= 4096 || (n <= 8192 && is_pow2(n))); };
-    return ok(rows) && ok(cols);
+    // a plane stays below 2 GiB: the kernels address it through 32-bit buffer offsets
+    auto ok = [](int n) { return n >= 2 && (n <= MI_FFT_MAX_ANY || (n <= MI_FFT_MAX_POW2 && is_pow2(n))); };
+    return ok(rows) && ok(cols) && (i64)rows * cols < ((i64)1 << 28);
 }
 
 size_t fft2d_workspace_bytes(int rows, int cols)

@@ -98,7 +98,7 @@ int launch_u8_to_complex(const void* in, void* r, void* g, void* b, int w, int h
 // transformed in place at full speed; may be null.
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s,
                  void* tmp = nullptr);
-// Any sizes (powers of two up to 8192, anything else up to 4096) with a caller workspace of
+// Any sizes (powers of two up to MI_FFT_MAX_POW2, anything else up to MI_FFT_MAX_ANY) with a caller workspace of
 // fft2d_workspace_bytes(rows, cols) bytes (0 when both are powers of two).
 int fft2d_size_supported(int rows, int cols);
 size_t fft2d_workspace_bytes(int rows, int cols);

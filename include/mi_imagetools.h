@@ -47,6 +47,10 @@ extern "C" {
 #define MI_ERR_SELFTEST (-6)      /* mi_selftest found a wrong result */
 
 #define MI_MAX_KERNEL_SIZE 31
+/* 2-D transforms: each of rows, cols is in [2, MI_FFT_MAX_ANY], or a power of two up to
+ * MI_FFT_MAX_POW2; a plane holds fewer than 2^28 points (2 GiB of interleaved fp32). */
+#define MI_FFT_MAX_ANY 8192
+#define MI_FFT_MAX_POW2 16384
 
 /* ---------------------------------------------------------------- library */
 
@@ -146,14 +150,14 @@ int mi_u8_to_complex_dev(const void *d_in, void *d_red, void *d_green, void *d_b
                          void *stream);
 /* cufftExecC2C (imageTools.cu:690-701, 741-751): unnormalised 2-D complex DFT, out of place or
  * in place, `batch` planes back to back.  direction -1 forward, +1 inverse.  rows and cols must
- * be powers of two in [2, 8192] for this entry point (no workspace). */
+ * be powers of two in [2, MI_FFT_MAX_POW2] for this entry point (no workspace). */
 #define MI_FFT_FORWARD (-1)
 #define MI_FFT_INVERSE (+1)
 int mi_fft2d_c2c_f32_dev(const void *d_in, void *d_out, int rows, int cols, int batch,
                          int direction, void *stream);
 /* cufftPlan2d + cufftExecC2C for any size (the reference plans whatever the image measures; its
- * demo input is 675x900, main.cpp:34-45): each of rows, cols is in [2, 4096], or a power of two
- * up to 8192.  Lengths that are not powers of two go through Bluestein's chirp-z transform and
+ * demo input is 675x900, main.cpp:34-45): each of rows, cols is in [2, MI_FFT_MAX_ANY], or a power
+ * of two up to MI_FFT_MAX_POW2.  Lengths that are not powers of two go through Bluestein's chirp-z transform and
  * need device scratch: mi_fft2d_workspace_bytes gives the size, the caller owns the buffer (cuFFT
  * keeps its work area inside the plan).  For powers of two the workspace is optional: the size is
  * 0 below 1024 rows and one plane (rows*cols*8) from 1024 rows on, where it lets an IN-PLACE
@@ -234,7 +238,7 @@ int mi_host_release(void);
  * cufftPlan2d(&plan, width, height, ...) (:688): the buffer is transformed as `w` rows of `h`
  * points while the shift and the filter index it as `h` rows of `w` -- the same thing for a
  * square image, and what reproduces the reference's own sample output for the 675x900 one
- * (tests/golden/).  Sizes: w, h in [2, 4096], or powers of two up to 8192. */
+ * (tests/golden/).  Sizes: w, h in [2, MI_FFT_MAX_ANY], or powers of two up to MI_FFT_MAX_POW2. */
 int mi_fft_highpass_u8x4(const uint8_t *in, uint8_t *out, int w, int h, float cutoff);
 /* The same on device images (d_in and d_out may be the same buffer), asynchronous on `stream`,
  * with the caller's scratch: three planes, three spectra and the transform workspace,

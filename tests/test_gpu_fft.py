@@ -35,7 +35,8 @@ def rand_plane(rows, cols, seed, batch=None):
 
 
 SHAPES = [(2, 2), (4, 8), (8, 2), (16, 16), (32, 16), (16, 64), (64, 64), (128, 32), (256, 256),
-          (512, 64), (64, 1024), (2048, 16), (16, 4096), (4096, 8), (8, 8192), (8192, 4)]
+          (512, 64), (64, 1024), (2048, 16), (16, 4096), (4096, 8), (8, 8192), (8192, 4),
+          (16384, 4), (8, 16384), (16384, 64)]
 
 
 @pytest.mark.parametrize("rows,cols", SHAPES)
@@ -55,7 +56,8 @@ def test_fft2d_forward_and_inverse_match_oracle(dev, golden, rows, cols):
 
 ODD_SHAPES = [(3, 5), (2, 7), (6, 10), (15, 17), (100, 64), (64, 100), (31, 1000), (243, 125),
               (900, 675), (2000, 2592 // 2), (4096, 3), (5, 8192), (4095, 6),
-              (40, 300), (500, 48)]     # padded lengths 128 and 1024: with the rest, every m from 8 to 8192
+              (40, 300), (500, 48),     # padded lengths 128 and 1024: with the rest, every m from 8 to 8192
+              (4097, 3), (6, 8191), (5000, 12)]     # m = 16384
 
 
 @pytest.mark.parametrize("rows,cols", ODD_SHAPES)
@@ -103,7 +105,11 @@ def test_fft2d_any_size_batch_roundtrip_and_errors(dev):
     assert rel_l2(back, x) <= REL_L2
     assert ops.fft2d_workspace_bytes(64, 128) == 0 and ops.fft2d_workspace_bytes(90, 68) > 0
     with pytest.raises(_lib.MiError):
-        ops.fft2d_workspace_bytes(5000, 64)                             # > 4096 and not a power of two
+        ops.fft2d_workspace_bytes(9000, 64)                             # > 8192 and not a power of two
+    with pytest.raises(_lib.MiError):
+        ops.fft2d_workspace_bytes(16384, 16384)                         # a plane of 2 GiB
+    with pytest.raises(_lib.MiError):
+        ops.fft2d_workspace_bytes(32768, 2)
     with pytest.raises(_lib.MiError):
         ops.fft2d(xd, workspace=torch.empty(16, dtype=torch.uint8, device=dev))
     with pytest.raises(_lib.MiError):                                   # the no-workspace entry point stays 2^k only
@@ -119,6 +125,30 @@ def test_fft_highpass_image_any_size(dev, golden):
     ref_u8, _ = golden.fft_highpass_image(img, 10.0)
     assert np.abs(out.astype(np.int16) - ref_u8.astype(np.int16)).max() <= 1
     assert (out[..., 3] == 255).all()
+
+
+def test_fft2d_photo_sized_plane(dev):
+    """A 24-megapixel plane (6000 x 4000: neither side a power of two, one above 4096): forward
+    transform against numpy.fft in double, then the round trip."""
+    rows, cols = 4000, 6000
+    x = rand_plane(rows, cols, 99)
+    xd = torch.from_numpy(x).to(dev)
+    ws = torch.empty(ops.fft2d_workspace_bytes(rows, cols), dtype=torch.uint8, device=dev)
+    f = ops.fft2d(xd, workspace=ws)
+    ref = np.fft.fft2(x.astype(np.complex128))
+    assert rel_l2(f.cpu().numpy(), ref) <= REL_L2
+    del ref
+    back = ops.fft2d(f, inverse=True, workspace=ws)
+    assert rel_l2((back / (rows * cols)).cpu().numpy(), x) <= REL_L2
+
+
+@pytest.mark.parametrize("w,h", [(4500, 20), (24, 5000)])
+def test_fft_highpass_image_wider_than_4096(dev, golden, w, h):
+    img = S.pattern_image("natural", w, h, 6)
+    out = np.empty_like(img)
+    ops.imageFFTImageGenerate(out, img, w, h)
+    ref_u8, _ = golden.fft_highpass_image(img, 10.0)
+    assert np.abs(out.astype(np.int16) - ref_u8.astype(np.int16)).max() <= 1
 
 
 @pytest.mark.parametrize("rows,cols,batch", [(1024, 64, 3), (2048, 16, 2), (4096, 8, 1), (1024, 1024, 2)])

@@ -1569,9 +1569,10 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     gaussian_kernel_1d(5, sigma, gw.w);
     const int grid = (int)((total + 3) / 4);
     aligned = aligned && band_fits_buffer_offsets(rpb, W);
+    const size_t pad = (size_t)std::max(0, std::min(tuning().chain_lds_pad_kib, 32)) << 10;
     if (!aligned) chain_kernel<0, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
-    else if (mrg == 2) chain_kernel<1, 2><<<grid, 256, 0, stream>>>(in, out, g, gw);
-    else chain_kernel<1, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
+    else if (mrg == 2) chain_kernel<1, 2><<<grid, 256, pad, stream>>>(in, out, g, gw);
+    else chain_kernel<1, 1><<<grid, 256, pad, stream>>>(in, out, g, gw);
     return hip_status(hipGetLastError(), "chain kernel launch");
 }
 

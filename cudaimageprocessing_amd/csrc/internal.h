@@ -29,7 +29,7 @@ struct Tuning {
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
     int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
-    int fft_col_tile = 1;         // MI_FFT_COL_TILE: single-pass column transform of tall planes in LDS tiles
+    int chain_lds_pad_kib = 8;    // MI_CHAIN_LDS_PAD_KIB: extra LDS per block of the fused chain (24 + 8 KiB: five blocks per CU, +2 %)
 };
 const Tuning& tuning();
 // name: the environment variable's name; returns false for an unknown name

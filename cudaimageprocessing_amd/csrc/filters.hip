@@ -1244,18 +1244,48 @@ __global__ __launch_bounds__(256) void gauss_direct_tile_kernel(const u32* __res
 // 13th smallest of the 25 flat taps per channel, alpha 255, same write set as the other stencils.
 // Wave march with one margin lane on each side (62 productive lanes, like the fused chain).
 // Work shared between neighbouring outputs (networks in median5_network.h):
-//   * every 5-pixel column is sorted once per row (sort5);
+//   * every 5-pixel column is sorted once per row, and the sort itself is shared between vertically
+//     adjacent rows (sorted pairs -> sorted quads -> one insertion per window, see the kernel body);
 //   * adjacent sorted columns are merged pairwise (merge55) -- a lane merges its columns (0,1)
-//     and (2,3), the pair to its right arrives by DPP;
+//     and (2,3), the pair to its right arrives from the neighbouring lane;
 //   * two outputs that share four columns share ranks 7..12 of those 20 values (ranks7to12):
 //     outputs 1,2 use the lane's own two pairs, output 3 and the right neighbour's output 0 use
 //     pair (2,3) and the neighbour's pair (0,1);
 //   * each output then picks the 6th smallest of those 6 values and its fifth column (select6of11).
-// R and B of a pixel share a register (one column per register); the G bytes of two adjacent
-// pixels share one, so a "column" of the G pass is a pair of columns (j, j+1) and its two halves
-// are outputs j and j+1 -- shifted pairs come from alignbit, as in the 3x3 kernel.
+// R and B of a pixel share a register (one column per register).  The G bytes of pixels (0, 2) and
+// of pixels (1, 3) share one each, so the two G output registers -- outputs (0, 2) and (1, 3) -- need
+// the packed columns X-2 .. X2 and X-1 .. X3 (X_j = columns j and j + 2): they share four of them
+// like two adjacent R,B outputs, and the composite columns come from the neighbours by alignbit.
+// Neighbour exchange: the R,B values cross lanes through the LDS crossbar (ds_bpermute: no LDS
+// memory, no vector-ALU issue slot -- this kernel is bound by vector issue), the G ones by DPP
+// (measured: all DPP 0.413 ms, all ds_bpermute 0.405, this mix 0.399 per 16 x 4K).
+#ifndef MI_MED5_BPERM
+#define MI_MED5_BPERM 1
+#endif
+#ifndef MI_MED5_MIX       // 0: every exchange as MI_MED5_BPERM says; 1: G by DPP; 2: R,B by DPP
+#define MI_MED5_MIX 1
+#endif
+#ifndef MI_MED5_WAVES
+#define MI_MED5_WAVES 1
+#endif
+#if MI_MED5_MIX == 1
+#define GL dl
+#define GR dr
+#define RL fl
+#define RR fr
+#elif MI_MED5_MIX == 2
+#define GL fl
+#define GR fr
+#define RL dl
+#define RR dr
+#else
+#define GL fl
+#define GR fr
+#define RL fl
+#define RR fr
+#endif
 template <int POL>
-__global__ __launch_bounds__(256) void median5_kernel(const u32* __restrict__ in,
+__global__ __launch_bounds__(256, MI_MED5_WAVES) void median5_kernel(const u32* __restrict__ in,
                                                       u32* __restrict__ out, const Geo g)
 {
     const WaveJob j = wave_job(g);
@@ -1266,76 +1296,123 @@ __global__ __launch_bounds__(256) void median5_kernel(const u32* __restrict__ in
     const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4, 1);
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
     constexpr u32 SEL_G = 0x0c050c01u;   // (byte 1 of src1) | (byte 1 of src0) << 16
+#if MI_MED5_BPERM
+    // neighbour exchange through the LDS crossbar (ds_bpermute: no LDS memory, no VALU issue slot)
+    // instead of DPP moves; the wrap-around lanes are margin lanes whose outputs are not stored
+    const int src_l = ((j.lane + 63) & 63) * 4, src_r = ((j.lane + 1) & 63) * 4;
+    auto fl = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(src_l, (int)v); };
+    auto fr = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(src_r, (int)v); };
+#else
+    auto fl = [](u32 v) { return from_left(v); };
+    auto fr = [](u32 v) { return from_right(v); };
+#endif
+    auto dl = [](u32 v) { return from_left(v); };
+    auto dr = [](u32 v) { return from_right(v); };
     auto mn = [](u32 a, u32 b) { return pk_min(a, b); };
     auto mx = [](u32 a, u32 b) { return pk_max(a, b); };
 
-    // slots 0..3 = (R | B << 16) of the lane's pixels, 4 = G of pixels 0,1, 5 = G of pixels 2,3
+    // slots 0..3 = (R | B << 16) of the lane's pixels, 4 = G of pixels 0,2, 5 = G of pixels 1,3
     auto unpack = [&](u32x4 p, u32 (&w)[6]) {
         w[0] = p.x & 0x00FF00FFu; w[1] = p.y & 0x00FF00FFu; w[2] = p.z & 0x00FF00FFu; w[3] = p.w & 0x00FF00FFu;
-        w[4] = __builtin_amdgcn_perm(p.y, p.x, SEL_G);
-        w[5] = __builtin_amdgcn_perm(p.w, p.z, SEL_G);
+        w[4] = __builtin_amdgcn_perm(p.z, p.x, SEL_G);
+        w[5] = __builtin_amdgcn_perm(p.w, p.y, SEL_G);
     };
 
-    u32 win[5][6];   // ring: input step i lives in slot i % 5 (loop unrolled by 5: static indices)
+    // Column sorts shared between vertically adjacent outputs.  Rows arrive one per step (arrival a =
+    // step + 4); consecutive arrivals (2m, 2m+1) are sorted once into a pair P_m, consecutive pairs are
+    // merged once into a quad Q_(m-1) (arrivals 2m-2 .. 2m+1), and the two windows that contain that quad
+    // -- arrivals 2m-3 .. 2m+1 and 2m-2 .. 2m+2 -- each insert their fifth row into it: 12 min/max per
+    // column and step where sorting five rows from scratch takes 18.  The loop is unrolled by four steps so
+    // that the pair ring, the ring of raw odd arrivals and every other index are compile-time constants.
+    auto sort2v = [&](u32 a, u32 b, u32 (&o)[2]) { o[0] = mn(a, b); o[1] = mx(a, b); };
+    auto merge22 = [&](const u32 (&p)[2], const u32 (&q)[2], u32 (&o)[4]) {
+        const u32 t1 = mx(p[0], q[0]), t2 = mn(p[1], q[1]);
+        o[0] = mn(p[0], q[0]); o[1] = mn(t1, t2); o[2] = mx(t1, t2); o[3] = mx(p[1], q[1]);
+    };
+    auto insert5 = [&](u32 x, const u32 (&a)[4], u32 (&o)[5]) {
+        o[0] = mn(a[0], x);
+        o[1] = mx(a[0], mn(a[1], x));
+        o[2] = mx(a[1], mn(a[2], x));
+        o[3] = mx(a[2], mn(a[3], x));
+        o[4] = mx(a[3], x);
+    };
+    u32 odd_raw[2][6], even_raw[6], P[2][6][2], Q[6][4];
+    {
+        u32 r0[6], r1[6], r2[6], r3[6];
+        unpack(io.load(mch.row(-2)), r0); unpack(io.load(mch.row(-1)), r1);
+        unpack(io.load(mch.row(0)), r2);  unpack(io.load(mch.row(1)), r3);
 #pragma unroll
-    for (int i = 0; i < 4; i++) unpack(io.load(mch.row(i - 2)), win[i]);
+        for (int k = 0; k < 6; k++) {
+            sort2v(r0[k], r1[k], P[0][k]); sort2v(r2[k], r3[k], P[1][k]);
+            merge22(P[0][k], P[1][k], Q[k]);
+            odd_raw[0][k] = r1[k]; odd_raw[1][k] = r3[k]; even_raw[k] = 0u;
+        }
+    }
     u32x4 nxt = io.load(mch.row(2));
-    for (int base = 0; base < mch.n; base += 5) {
+    for (int base = 0; base < mch.n; base += 4) {
 #pragma unroll
-        for (int s = 0; s < 5; s++) {
+        for (int s = 0; s < 4; s++) {
             const int i = base + s;
             if (i < mch.n) {
             const int y = mch.row(i);
-            unpack(nxt, win[(s + 4) % 5]);
+            u32 cur[6];
+            unpack(nxt, cur);
             nxt = io.load(mch.row(i + 3));
             u32 c[6][5];   // sorted columns
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-#pragma unroll
-                for (int r = 0; r < 5; r++) c[k][r] = win[r][k];
-                sort5(c[k], mn, mx);
+                if (s % 2 == 0) {          // even arrival 2m+2: the quad of the step before plus this row
+                    insert5(cur[k], Q[k], c[k]);
+                    even_raw[k] = cur[k];
+                } else {                   // odd arrival 2m+1, m = 2 + i/2 (its parity is s/2 for base % 4 == 0)
+                    const int mp = s / 2;
+                    sort2v(even_raw[k], cur[k], P[mp][k]);
+                    merge22(P[mp ^ 1][k], P[mp][k], Q[k]);
+                    insert5(odd_raw[mp][k], Q[k], c[k]);
+                    odd_raw[mp][k] = cur[k];
+                }
             }
-            u32 rb[4], g01, g23;
+            u32 rb[4], g02, g13;
             {   // ---- R,B
                 u32 m01[10], m23[10], rm01[10], sa[6], sb[6], lsb[6], lc3[5], rc0[5];
                 merge55(c[0], c[1], m01, mn, mx);
                 merge55(c[2], c[3], m23, mn, mx);
 #pragma unroll
-                for (int k = 0; k < 10; k++) rm01[k] = from_right(m01[k]);
+                for (int k = 0; k < 10; k++) rm01[k] = RR(m01[k]);
                 ranks7to12(m01, m23, sa, mn, mx);      // columns 0..3
                 ranks7to12(m23, rm01, sb, mn, mx);     // columns 2..5
 #pragma unroll
-                for (int k = 0; k < 6; k++) lsb[k] = from_left(sb[k]);   // columns -2..1
+                for (int k = 0; k < 6; k++) lsb[k] = RL(sb[k]);   // columns -2..1
 #pragma unroll
-                for (int k = 0; k < 5; k++) { lc3[k] = from_left(c[3][k]); rc0[k] = from_right(c[0][k]); }
+                for (int k = 0; k < 5; k++) { lc3[k] = RL(c[3][k]); rc0[k] = RR(c[0][k]); }
                 rb[0] = select6of11(lsb, c[2], mn, mx);   // window -2..2
                 rb[1] = select6of11(sa, lc3, mn, mx);     // window -1..3
                 rb[2] = select6of11(sa, rc0, mn, mx);     // window  0..4
                 rb[3] = select6of11(sb, c[1], mn, mx);    // window  1..5
             }
-            {   // ---- G: pair columns P_j = (column j, column j+1); own P0 = c[4], P2 = c[5]
-                u32 p1[5], p3[5], p4[5], n01[10], n23[10], ln23[10], s0[6], s2[6];
+            {   // ---- G: packed columns X_j = (column j, column j + 2); own X0 = c[4], X1 = c[5].  Outputs (0, 2)
+                // take X-2 .. X2 and outputs (1, 3) take X-1 .. X3: the two registers share X-1 .. X2 exactly as
+                // two adjacent R,B outputs share four columns -- two merges, ONE ranks7to12, two selections
+                u32 xm2[5], xm1[5], x2[5], x3[5], ma[10], mb[10], sg[6];
 #pragma unroll
                 for (int k = 0; k < 5; k++) {
-                    p4[k] = from_right(c[4][k]);
-                    p1[k] = __builtin_amdgcn_alignbit(c[5][k], c[4][k], 16);
-                    p3[k] = __builtin_amdgcn_alignbit(p4[k], c[5][k], 16);
+                    xm2[k] = __builtin_amdgcn_alignbit(c[4][k], GL(c[4][k]), 16);   // (left lane's G2, G0)
+                    xm1[k] = __builtin_amdgcn_alignbit(c[5][k], GL(c[5][k]), 16);   // (left lane's G3, G1)
+                    x2[k] = __builtin_amdgcn_alignbit(GR(c[4][k]), c[4][k], 16);    // (G2, right lane's G0)
+                    x3[k] = __builtin_amdgcn_alignbit(GR(c[5][k]), c[5][k], 16);    // (G3, right lane's G1)
                 }
-                merge55(c[4], p1, n01, mn, mx);
-                merge55(c[5], p3, n23, mn, mx);
-#pragma unroll
-                for (int k = 0; k < 10; k++) ln23[k] = from_left(n23[k]);   // pair columns -2, -1
-                ranks7to12(ln23, n01, s0, mn, mx);
-                ranks7to12(n01, n23, s2, mn, mx);
-                g01 = select6of11(s0, c[5], mn, mx);      // pair columns -2..2: outputs 0, 1
-                g23 = select6of11(s2, p4, mn, mx);        // pair columns  0..4: outputs 2, 3
+                merge55(xm1, c[4], ma, mn, mx);
+                merge55(c[5], x2, mb, mn, mx);
+                ranks7to12(ma, mb, sg, mn, mx);
+                g02 = select6of11(sg, xm2, mn, mx);       // outputs 0, 2
+                g13 = select6of11(sg, x3, mn, mx);        // outputs 1, 3
             }
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32x4 o;
-            o.x = __builtin_amdgcn_perm(g01, rb[0], 0x0d020400u) & xm[0] & rowm;
-            o.y = __builtin_amdgcn_perm(g01, rb[1], 0x0d020600u) & xm[1] & rowm;
-            o.z = __builtin_amdgcn_perm(g23, rb[2], 0x0d020400u) & xm[2] & rowm;
-            o.w = __builtin_amdgcn_perm(g23, rb[3], 0x0d020600u) & xm[3] & rowm;
+            o.x = __builtin_amdgcn_perm(g02, rb[0], 0x0d020400u) & xm[0] & rowm;
+            o.y = __builtin_amdgcn_perm(g13, rb[1], 0x0d020400u) & xm[1] & rowm;
+            o.z = __builtin_amdgcn_perm(g02, rb[2], 0x0d020600u) & xm[2] & rowm;
+            o.w = __builtin_amdgcn_perm(g13, rb[3], 0x0d020600u) & xm[3] & rowm;
             io.store(y, o);
             }
         }

@@ -93,7 +93,7 @@ MI_DEV void red_pairs(u32x4 p, u32& r01, u32& r23)
 #define MI_SEP_BURST 3    // rows per request burst of the separable Gaussian (fp32) and mean kernels; 0: one row ahead, in registers
 #endif
 #ifndef MI_FEED_K
-#define MI_FEED_K 0       // rows per request burst of the 3x3 march kernels (RowFeed in common.h); 0: one row ahead, in registers
+#define MI_FEED_K 2       // rows per request burst of the 3x3 march kernels (RowFeed in common.h); 0: one row ahead, in registers
                           // (measured: with their 6-row bands bursts of 2 change nothing, bursts of 3 or 4 cost 3..5 %)
 #endif
 
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void gauss_sep_kernel(const 
 
     // input rows in bursts through a per-wave LDS ring (RowFeed, common.h) with the 4-pixel groups beside the strip
     // (3x3: 6-row bands, where bursts gain nothing and the ring would cap the occupancy: one row ahead, in registers)
-    typedef RowFeed<POL, (R == 1 ? 0 : MI_SEP_BURST), 4 * HOPS> Feed;
+    typedef RowFeed<POL, (R == 1 ? MI_FEED_K : MI_SEP_BURST), 4 * HOPS> Feed;
     typedef typename Feed::Row RowIn;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     Feed feed(io, mch, ring, j.lane);
@@ -1450,6 +1450,19 @@ __global__ __launch_bounds__(256) void synth_kernel(u32* __restrict__ out, uint6
 }
 
 // ============================================================================ launcher
+// Extra dynamic LDS per block: it holds nothing, it caps the blocks a CU runs at one time.  With their
+// input rows arriving in bursts the march kernels run fastest with about three waves per SIMD
+// (tools/marchbench.hip: fewer concurrent fronts, each denser); the request is within the 64 KiB a
+// kernel may ask for without an attribute.
+static size_t lds_pad(int r)
+{
+    // measured per 16 x 4K: 3x3 kernels 0.192-0.196 -> 0.187-0.190 ms with 24 KiB (three blocks per CU) and
+    // 12-row bands; Gaussian and mean 5x5 0.199 -> 0.197 / 0.194 with 16, mean 7x7 0.200 -> 0.194 with 24;
+    // the wider kernels are capped by their registers already
+    int kib = r == 1 ? tuning().lds_pad_kib : tuning().sep_lds_pad_kib;
+    if (r > 1 && kib < 0) kib = r == 2 ? 16 : r <= 4 ? 24 : 0;
+    return (size_t)std::max(0, std::min(kib, 40)) << 10;
+}
 static int grid_cap() { return 256 * 8; }  // 256 CUs x 8 blocks of 256 threads
 
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s)
@@ -1516,7 +1529,7 @@ template <int R>
 static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out,
                              const Geo& g, const GaussW& gw)
 {
-#define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+#define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, lds_pad(R), s>>>(in, out, g, gw)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }
@@ -1594,7 +1607,7 @@ static u32 mean_magic32(int k)
 template <int R>
 static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic)
 {
-#define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, magic)
+#define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, lds_pad(R), s>>>(in, out, g, magic)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }
@@ -1767,13 +1780,13 @@ int launch_filter(const FilterArgs& a)
     g.strips = median5 ? (W + 247) / 248 : (W + 255) / 256;
     // Rows per band.  Short bands keep the waves that run together on nearby rows, so the
     // access stream stays close to a front-to-back sweep (measured on MI355X: 3x3 filters peak
-    // at 4-6 rows per band, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
+    // at 6 or 12 rows per band with rows requested in bursts of two, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
     // are shared with the neighbouring band through L2 (see March), not re-fetched from HBM.
     // A taller band amortises the row pass of a wide Gaussian over more output rows.
     int rpb = tuning().rows_per_band;
     if (rpb <= 0) {
         const int r = (a.filter == MI_FILTER_GAUSSIAN || a.filter == MI_FILTER_MEAN || direct_march) ? a.ksize / 2 : 1;
-        rpb = r == 1 ? 6 : std::min(10 * r, 64);
+        rpb = r == 1 ? 12 : std::min(10 * r, 64);
         if (median5) rpb = 32;   // VALU-bound: amortise the 4 extra rows of a band
         // wide Gaussians: 2R extra row passes per band, two waves per SIMD -> taller bands, fewer waves
         const i64 min_waves = r >= 5 ? 2048 : 4096;
@@ -1794,14 +1807,14 @@ int launch_filter(const FilterArgs& a)
     switch (a.filter) {
     case MI_FILTER_SOBEL:
     {
-#define MI_L(P) sobel_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+#define MI_L(P) sobel_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }
         break;
     case MI_FILTER_MEAN:
         if (a.ksize == 3) {
-#define MI_L(P) mean3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+#define MI_L(P) mean3_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
             MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
         } else {
@@ -1821,7 +1834,7 @@ int launch_filter(const FilterArgs& a)
     case MI_FILTER_MEDIAN:
     {
 #define MI_L(P) if (median5) median5_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g); \
-                else median3_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g)
+                else median3_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }

@@ -24,6 +24,8 @@ F = {
     "gauss15": lambda: ops.gaussian_blur(frames, 15, 2.5, out),
     "mean5": lambda: ops.mean_blur(frames, 5, out),
     "mean7": lambda: ops.mean_blur(frames, 7, out),
+    "mean9": lambda: ops.mean_blur(frames, 9, out),
+    "mean13": lambda: ops.mean_blur(frames, 13, out),
     "mean11": lambda: ops.mean_blur(frames, 11, out),
     "mean15": lambda: ops.mean_blur(frames, 15, out),
     "median5": lambda: ops.median_blur(frames, 5, out),

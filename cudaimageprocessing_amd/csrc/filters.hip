@@ -586,7 +586,6 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
                 pair[jp][c] = __builtin_amdgcn_perm(col[2 * jp + 1], col[2 * jp], 0x0c040c00u + (u32)c * 0x00010001u);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            constexpr int dummy = 0; (void)dummy;
             const int ci0 = k - R + 8;                          // the first tap's column, counted from -8
             const u32* wcr = (ci0 % 2 == 0) ? gw.wc_even : gw.wc_odd;
 #pragma unroll
@@ -766,6 +765,117 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
 #pragma unroll
             for (int e = 0; e < 8; e++) cs[e] = pk_sub(cs[e], win[s % K][e]);   // drop row y-R
             }
+        }
+    }
+}
+
+// ============================================================================ mean 17x17 .. 31x31
+// A window of K = 2R+1 row sums no longer fits the registers (31 rows x 8), so this kernel keeps none:
+// the running column sums gain the row that enters the window and lose the row that leaves it, and the
+// leaving row is simply READ AGAIN (it was loaded K steps earlier by the same wave: an L2 / Infinity
+// Cache hit) and its horizontal sums recomputed.  The horizontal box sum is a difference of prefix
+// sums: packed 16-bit (R|B<<16, G|A<<16) inclusive prefix sums across the whole wave -- three adds in
+// the lane, a six-step DPP scan of the lane totals -- which may wrap around, because only differences
+// P[x+R] - P[x-R-1] <= 31*255 are ever used; those two prefix values come from the lanes about R/4
+// away through ds_bpermute.  Four margin lanes on each side feed their neighbours only (56 productive
+// lanes, 224-pixel strips), so the same code serves every R <= 15.  Column sums are 32-bit (31*31*255
+// needs 18 bits); the division is the exact multiply-high by ceil(2^32/k^2) that the host verified
+// for every reachable sum.  Integer arithmetic throughout: bit-exact, any decomposition.
+MI_DEV u32 wave_scan_pk16(u32 v)
+{   // inclusive prefix sum over the 64 lanes, per 16-bit half (the gfx9 DPP scan: row shifts, then row broadcasts)
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = pk_add(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int R, int POL>
+__global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict__ in, u32* __restrict__ out,
+                                                          const Geo g, const u32 magic32)
+{
+    static_assert(R >= 1 && R <= 15, "four margin lanes cover a reach of 16 pixels");
+    constexpr int MRG = 4, OUTW = 4 * (64 - 2 * MRG);
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    const int cx = j.strip * OUTW - 4 * MRG + 4 * j.lane;
+    const March mch = make_march(g, j);
+    const RowIO<POL> io(in, out, g, j, mch, j.strip * OUTW - 4 * MRG, MRG);
+    const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
+    // source lanes of the two prefix values of pixel k: column k+R is pixel (k+R)%4 of lane +(k+R)/4,
+    // column k-R-1 is pixel (k-R-1) mod 4 of lane -((R+1-k)+3)/4
+    int hi_addr[4], lo_addr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        hi_addr[k] = ((j.lane + (k + R) / 4) & 63) * 4;
+        lo_addr[k] = ((j.lane - (R + 1 - k + 3) / 4) & 63) * 4;
+    }
+    // h[2k] = (R,B), h[2k+1] = (G,A) sums over columns k-R .. k+R of one row, for the lane's pixel k
+    auto hrow = [&](u32x4 p, u32 (&h)[8]) {
+        const u32 px[4] = {p.x, p.y, p.z, p.w};
+        u32 pl[4], ph[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) unpack_px(px[k], pl[k], ph[k]);
+#pragma unroll
+        for (int k = 1; k < 4; k++) { pl[k] = pk_add(pl[k], pl[k - 1]); ph[k] = pk_add(ph[k], ph[k - 1]); }
+        const u32 el = pk_sub(wave_scan_pk16(pl[3]), pl[3]), eh = pk_sub(wave_scan_pk16(ph[3]), ph[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { pl[k] = pk_add(pl[k], el); ph[k] = pk_add(ph[k], eh); }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = (k + R) % 4, b = ((k - R - 1) % 4 + 4) % 4;
+            const u32 al = (u32)__builtin_amdgcn_ds_bpermute(hi_addr[k], (int)pl[a]);
+            const u32 ah = (u32)__builtin_amdgcn_ds_bpermute(hi_addr[k], (int)ph[a]);
+            const u32 bl = (u32)__builtin_amdgcn_ds_bpermute(lo_addr[k], (int)pl[b]);
+            const u32 bh = (u32)__builtin_amdgcn_ds_bpermute(lo_addr[k], (int)ph[b]);
+            h[2 * k] = pk_sub(al, bl);
+            h[2 * k + 1] = pk_sub(ah, bh);
+        }
+    };
+    // column sums: S[3k + c], c = R, G, B of pixel k
+    u32 S[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    auto add_row = [&](const u32 (&h)[8]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            S[3 * k] += h[2 * k] & 0xFFFFu; S[3 * k + 2] += h[2 * k] >> 16; S[3 * k + 1] += h[2 * k + 1] & 0xFFFFu;
+        }
+    };
+    auto sub_row = [&](const u32 (&h)[8]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            S[3 * k] -= h[2 * k] & 0xFFFFu; S[3 * k + 2] -= h[2 * k] >> 16; S[3 * k + 1] -= h[2 * k + 1] & 0xFFFFu;
+        }
+    };
+    // rows row(-R) .. row(R-1) prime the sums; step i then adds row(i+R), stores, and drops row(i-R)
+    {
+        u32x4 nxt = io.load(mch.row(-R));
+        for (int t = -R; t < R; t++) {
+            const u32x4 cur = nxt;
+            nxt = io.load(mch.row(t + 1));      // the last one is row(R): step 0's entering row
+            u32 h[8];
+            hrow(cur, h);
+            add_row(h);
+        }
+        u32x4 nxt_in = nxt, nxt_out = io.load(mch.row(-R));
+        for (int i = 0; i < mch.n; i++) {
+            const int y = mch.row(i);
+            const u32x4 cin = nxt_in, cout = nxt_out;
+            nxt_in = io.load(mch.row(i + 1 + R));
+            nxt_out = io.load(mch.row(i + 1 - R));
+            u32 h[8];
+            hrow(cin, h);
+            add_row(h);
+            const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
+            u32 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = (__umulhi(S[3 * k], magic32) | (__umulhi(S[3 * k + 1], magic32) << 8) |
+                        (__umulhi(S[3 * k + 2], magic32) << 16) | 0xFF000000u) & xm[k] & rowm;
+            io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+            hrow(cout, h);
+            sub_row(h);
         }
     }
 }
@@ -1605,6 +1715,14 @@ static u32 mean_magic32(int k)
 }
 
 template <int R>
+static void launch_mean_prefix(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic32)
+{
+#define MI_L(P) mean_prefix_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, magic32)
+    MI_POLICY_CASES(pol, MI_L)
+#undef MI_L
+}
+
+template <int R>
 static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic)
 {
 #define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, lds_pad(R), s>>>(in, out, g, magic)
@@ -1709,7 +1827,9 @@ int launch_filter(const FilterArgs& a)
     // generic one-thread-per-pixel kernels
     const bool direct_march = a.filter == MI_FILTER_GAUSSIAN_DIRECT && a.ksize >= 3 && a.ksize <= 7;
     const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT && !direct_march;
-    const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15);
+    const bool mean_prefix = a.filter == MI_FILTER_MEAN && a.ksize >= 17 && a.ksize <= 31 && mean_magic32(a.ksize) &&
+                             tuning().mean_prefix;
+    const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15) && !mean_prefix;
     if (mean_generic && a.ksize >= 17 && a.ksize <= 31 && mean_magic32(a.ksize)) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
         const int r = a.ksize / 2;
@@ -1777,7 +1897,7 @@ int launch_filter(const FilterArgs& a)
     // wave-march kernels
     const bool median5 = a.filter == MI_FILTER_MEDIAN && a.ksize == 5;
     // a wave covers 64 lanes x 4 pixels; the 5x5 median keeps one margin lane on each side
-    g.strips = median5 ? (W + 247) / 248 : (W + 255) / 256;
+    g.strips = median5 ? (W + 247) / 248 : mean_prefix ? (W + 223) / 224 : (W + 255) / 256;
     // Rows per band.  Short bands keep the waves that run together on nearby rows, so the
     // access stream stays close to a front-to-back sweep (measured on MI355X: 3x3 filters peak
     // at 6 or 12 rows per band with rows requested in bursts of two, the 5x5 Gaussian at 16-24); the halo rows a short band re-reads
@@ -1817,6 +1937,18 @@ int launch_filter(const FilterArgs& a)
 #define MI_L(P) mean3_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
             MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
+        } else if (mean_prefix) {
+            const u32 m32 = mean_magic32(a.ksize);
+            switch (a.ksize / 2) {
+            case 8: launch_mean_prefix<8>(pol, grid, a.stream, in, out, g, m32); break;
+            case 9: launch_mean_prefix<9>(pol, grid, a.stream, in, out, g, m32); break;
+            case 10: launch_mean_prefix<10>(pol, grid, a.stream, in, out, g, m32); break;
+            case 11: launch_mean_prefix<11>(pol, grid, a.stream, in, out, g, m32); break;
+            case 12: launch_mean_prefix<12>(pol, grid, a.stream, in, out, g, m32); break;
+            case 13: launch_mean_prefix<13>(pol, grid, a.stream, in, out, g, m32); break;
+            case 14: launch_mean_prefix<14>(pol, grid, a.stream, in, out, g, m32); break;
+            default: launch_mean_prefix<15>(pol, grid, a.stream, in, out, g, m32); break;
+            }
         } else {
             const u32 magic = mean_magic(a.ksize);
             if (!magic) return fail(MI_ERR_UNSUPPORTED, "no exact reciprocal for mean kernel size %d", a.ksize);

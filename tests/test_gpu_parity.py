@@ -278,6 +278,7 @@ def test_decomposition_does_not_change_results(dev):
            "gauss5": lambda t: ops.gaussian_blur(t, 5, 1.0), "gauss15": lambda t: ops.gaussian_blur(t, 15, 2.5),
            "median5": lambda t: ops.median_blur(t, 5), "mean7": lambda t: ops.mean_blur(t, 7),
            "mean15": lambda t: ops.mean_blur(t, 15), "gauss11": lambda t: ops.gaussian_blur(t, 11, 2.0),
+           "mean17": lambda t: ops.mean_blur(t, 17), "mean31": lambda t: ops.mean_blur(t, 31),
            "direct5": lambda t: ops.gaussian_blur(t, 5, 1.0, direct=True),
            "direct7": lambda t: ops.gaussian_blur(t, 7, 1.5, direct=True)}
     with ops.tuning(MI_ROWS_PER_BAND=32, MI_CHAIN_ROWS_PER_BAND=32):
@@ -288,6 +289,24 @@ def test_decomposition_does_not_change_results(dev):
             for k, fn in fns.items():
                 assert torch.equal(fn(img), ref[k]), (k, rpb)
             assert torch.equal(ops.fused_chain(img), ref_chain), rpb
+
+
+@pytest.mark.parametrize("k", [17, 23, 31])
+def test_wide_mean_strips_tiles_and_oracle(dev, golden, k):
+    """Mean 17x17..31x31 (the prefix-sum march): row strips filtered from their rows plus halo reproduce the
+    single launch, which equals the oracle and the LDS-tile kernel it replaced (MI_MEAN_PREFIX=0)."""
+    w, h = 1000, 300
+    img = ops.synth(k, w, h)
+    whole = ops.mean_blur(img, k)
+    assert np.array_equal(host(whole), golden.meanblur(host(img), k))
+    with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
+        assert torch.equal(ops.mean_blur(img, k), whole)
+    halo = ops.halo_rows(_lib.FILTER_MEAN, k)
+    for y0, y1 in ((0, 100), (100, 117), (117, 300)):
+        r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+        out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+        ops.filter_strip(_lib.FILTER_MEAN, img[r0:r1], out, w, h, r0, y0, y1, k, 0.0)
+        assert torch.equal(out, whole[y0:y1]), (y0, y1)
 
 
 def test_large_batch_properties(dev):

@@ -28,6 +28,9 @@ F = {
     "mean13": lambda: ops.mean_blur(frames, 13, out),
     "mean11": lambda: ops.mean_blur(frames, 11, out),
     "mean15": lambda: ops.mean_blur(frames, 15, out),
+    "mean17": lambda: ops.mean_blur(frames, 17, out),
+    "mean23": lambda: ops.mean_blur(frames, 23, out),
+    "mean31": lambda: ops.mean_blur(frames, 31, out),
     "median5": lambda: ops.median_blur(frames, 5, out),
     "chain": lambda: ops.fused_chain(frames, 1.0, out),
 }

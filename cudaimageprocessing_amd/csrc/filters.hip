@@ -1564,8 +1564,10 @@ __global__ __launch_bounds__(256) void synth_kernel(u32* __restrict__ out, uint6
 // input rows arriving in bursts the march kernels run fastest with about three waves per SIMD
 // (tools/marchbench.hip: fewer concurrent fronts, each denser); the request is within the 64 KiB a
 // kernel may ask for without an attribute.
-static size_t lds_pad(int r)
+constexpr i64 LDS_PAD_MIN_WAVES = 12288;   // a smaller launch wants every wave slot it can get (measured on 1 and 4 4K frames)
+static size_t lds_pad(int r, i64 total_waves)
 {
+    if (total_waves < LDS_PAD_MIN_WAVES) return 0;
     // measured per 16 x 4K: 3x3 kernels 0.192-0.196 -> 0.187-0.190 ms with 24 KiB (three blocks per CU) and
     // 12-row bands; Gaussian and mean 5x5 0.199 -> 0.197 / 0.194 with 16, mean 7x7 0.200 -> 0.194 with 24;
     // the wider kernels are capped by their registers already
@@ -1639,7 +1641,7 @@ template <int R>
 static void launch_gauss_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out,
                              const Geo& g, const GaussW& gw)
 {
-#define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, lds_pad(R), s>>>(in, out, g, gw)
+#define MI_L(P) gauss_sep_kernel<R, P><<<grid, 256, lds_pad(R, g.total_waves), s>>>(in, out, g, gw)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }
@@ -1725,7 +1727,7 @@ static void launch_mean_prefix(int pol, int grid, hipStream_t s, const u32* in, 
 template <int R>
 static void launch_mean_sep(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, u32 magic)
 {
-#define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, lds_pad(R), s>>>(in, out, g, magic)
+#define MI_L(P) mean_sep_kernel<R, P><<<grid, 256, lds_pad(R, g.total_waves), s>>>(in, out, g, magic)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }
@@ -1777,7 +1779,7 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     gaussian_kernel_1d(5, sigma, gw.w);
     const int grid = (int)((total + 3) / 4);
     aligned = aligned && band_fits_buffer_offsets(rpb, W);
-    const size_t pad = (size_t)std::max(0, std::min(tuning().chain_lds_pad_kib, 32)) << 10;
+    const size_t pad = total < LDS_PAD_MIN_WAVES ? 0 : (size_t)std::max(0, std::min(tuning().chain_lds_pad_kib, 32)) << 10;
     if (!aligned) chain_kernel<0, 1><<<grid, 256, 0, stream>>>(in, out, g, gw);
     else if (mrg == 2) chain_kernel<1, 2><<<grid, 256, pad, stream>>>(in, out, g, gw);
     else chain_kernel<1, 1><<<grid, 256, pad, stream>>>(in, out, g, gw);
@@ -1927,14 +1929,14 @@ int launch_filter(const FilterArgs& a)
     switch (a.filter) {
     case MI_FILTER_SOBEL:
     {
-#define MI_L(P) sobel_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
+#define MI_L(P) sobel_kernel<P><<<grid, 256, lds_pad(1, g.total_waves), a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }
         break;
     case MI_FILTER_MEAN:
         if (a.ksize == 3) {
-#define MI_L(P) mean3_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
+#define MI_L(P) mean3_kernel<P><<<grid, 256, lds_pad(1, g.total_waves), a.stream>>>(in, out, g)
             MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
         } else if (mean_prefix) {
@@ -1966,7 +1968,7 @@ int launch_filter(const FilterArgs& a)
     case MI_FILTER_MEDIAN:
     {
 #define MI_L(P) if (median5) median5_kernel<P><<<grid, 256, 0, a.stream>>>(in, out, g); \
-                else median3_kernel<P><<<grid, 256, lds_pad(1), a.stream>>>(in, out, g)
+                else median3_kernel<P><<<grid, 256, lds_pad(1, g.total_waves), a.stream>>>(in, out, g)
         MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
     }

@@ -991,6 +991,9 @@ __global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __re
 #ifndef MI_CHAIN_WAVES
 #define MI_CHAIN_WAVES 1  // waves per SIMD the register allocation must allow (1: whatever the code needs)
 #endif
+#ifndef MI_CHAIN_BPERM
+#define MI_CHAIN_BPERM 0
+#endif
 template <int POL, int MRG>
 __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* __restrict__ in,
                                                     u32* __restrict__ out, const Geo g,
@@ -1007,6 +1010,18 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
     const u32 xm[4] = {xmask(cx, g.W), xmask(cx + 1, g.W), xmask(cx + 2, g.W), xmask(cx + 3, g.W)};
     const u32 pm01 = (xm[0] & 0xFFFFu) | (xm[1] & 0xFFFF0000u), pm23 = (xm[2] & 0xFFFFu) | (xm[3] & 0xFFFF0000u);
     auto rowmask = [&](int y) { return (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u; };
+    // neighbour exchange: DPP wave shifts, or (stage groups named by the bits of MI_CHAIN_BPERM: 1 gray, 2 median,
+    // 4 Sobel) the LDS crossbar -- ds_bpermute takes no vector-ALU issue slot; what wraps around into the
+    // edge lanes only reaches margin lanes
+    const int src_l = ((j.lane + 63) & 63) * 4, src_r = ((j.lane + 1) & 63) * 4;
+    auto xl = [&](u32 v, auto tag) {
+        if constexpr ((MI_CHAIN_BPERM & decltype(tag)::value) != 0) return (u32)__builtin_amdgcn_ds_bpermute(src_l, (int)v);
+        else return from_left(v);
+    };
+    auto xr = [&](u32 v, auto tag) {
+        if constexpr ((MI_CHAIN_BPERM & decltype(tag)::value) != 0) return (u32)__builtin_amdgcn_ds_bpermute(src_r, (int)v);
+        else return from_right(v);
+    };
 
     // stage 1+2a: grayscale of 4 pixels (as floats holding integers), then the Gaussian row pass
     // (two pixels per packed fp32 operation; each lane of a packed operation is the scalar one)
@@ -1026,10 +1041,10 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
             f[2 + 2 * q] = __builtin_floorf(v.x);        // == (float)(uchar)v, v >= 0
             f[3 + 2 * q] = __builtin_floorf(v.y);
         }
-        f[0] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[4])));
-        f[1] = __builtin_bit_cast(float, from_left(__builtin_bit_cast(u32, f[5])));
-        f[6] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[2])));
-        f[7] = __builtin_bit_cast(float, from_right(__builtin_bit_cast(u32, f[3])));
+        f[0] = __builtin_bit_cast(float, xl(__builtin_bit_cast(u32, f[4]), std::integral_constant<int, 1>{}));
+        f[1] = __builtin_bit_cast(float, xl(__builtin_bit_cast(u32, f[5]), std::integral_constant<int, 1>{}));
+        f[6] = __builtin_bit_cast(float, xr(__builtin_bit_cast(u32, f[2]), std::integral_constant<int, 1>{}));
+        f[7] = __builtin_bit_cast(float, xr(__builtin_bit_cast(u32, f[3]), std::integral_constant<int, 1>{}));
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             f32x2 sum = gw.w[0] * f32x2{f[2 * q], f[2 * q + 1]};
@@ -1101,8 +1116,9 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
             u32 med01 = 0u, med23 = 0u;
             if constexpr (MI_CHAIN_DBG == 3) { med01 = G01[(s + 4) % 5]; med23 = G23[(s + 4) % 5]; } else
             if (i >= 2) {
-                const u32 lL = from_left(l23), mL = from_left(m23), hL = from_left(h23);
-                const u32 lR = from_right(l01), mR = from_right(m01), hR = from_right(h01);
+                constexpr std::integral_constant<int, 2> T2{};
+                const u32 lL = xl(l23, T2), mL = xl(m23, T2), hL = xl(h23, T2);
+                const u32 lR = xr(l01, T2), mR = xr(m01, T2), hR = xr(h01, T2);
                 const u32 la = __builtin_amdgcn_alignbit(l01, lL, 16), lb = __builtin_amdgcn_alignbit(l23, l01, 16), lc = __builtin_amdgcn_alignbit(lR, l23, 16);
                 const u32 ma = __builtin_amdgcn_alignbit(m01, mL, 16), mb = __builtin_amdgcn_alignbit(m23, m01, 16), mc = __builtin_amdgcn_alignbit(mR, m23, 16);
                 const u32 ha = __builtin_amdgcn_alignbit(h01, hL, 16), hb = __builtin_amdgcn_alignbit(h23, h01, 16), hc = __builtin_amdgcn_alignbit(hR, h23, 16);
@@ -1117,8 +1133,9 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
                 const u32 mt01 = M01[(s + 3) % 5], mt23 = M23[(s + 3) % 5], mm01 = M01[(s + 4) % 5], mm23 = M23[(s + 4) % 5];
                 const u32 V01 = h_fma2(mm01, h_add(mt01, med01)), V23 = h_fma2(mm23, h_add(mt23, med23));
                 const u32 D01 = h_sub(med01, mt01), D23 = h_sub(med23, mt23);
-                const u32 VL = from_left(V23), VR = from_right(V01);
-                const u32 DL = from_left(D23), DR = from_right(D01);
+                constexpr std::integral_constant<int, 4> T4{};
+                const u32 VL = xl(V23, T4), VR = xr(V01, T4);
+                const u32 DL = xl(D23, T4), DR = xr(D01, T4);
                 const u32 Va = __builtin_amdgcn_alignbit(V01, VL, 16);
                 const u32 Vb = __builtin_amdgcn_alignbit(V23, V01, 16);
                 const u32 Vc = __builtin_amdgcn_alignbit(VR, V23, 16);

@@ -62,8 +62,11 @@ report(f"Sobel ({C})", ":255-285", px, 8, lambda: ops.sobel(fr, out))
 report(f"mean 3x3 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 3, out))
 report(f"mean 7x7 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 7, out), 20)
 report(f"mean 15x15 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 15, out), 20)
-report(f"mean 17x17, LDS tiles ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 10, "sizes 17..31: tile + sliding sums in LDS")
-report(f"mean 31x31, LDS tiles ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 10, "sizes 17..31")
+report(f"mean 17x17, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 20, "sizes 17..31: no row window, the leaving row is read again")
+report(f"mean 31x31, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "sizes 17..31")
+ops.set_tuning("MI_MEAN_PREFIX", 0)
+report(f"mean 31x31, LDS tiles (round 1's kernel, MI_MEAN_PREFIX=0) ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 10, "kept as a cross-check")
+ops.set_tuning("MI_MEAN_PREFIX", 1)
 report(f"median 3x3 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 3, out))
 report(f"median 5x5 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 5, out), 20, "VALU-bound")
 for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)):

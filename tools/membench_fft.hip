@@ -100,6 +100,65 @@ void run_coltile(const char* name, const float* in, float* out, int planes, int 
            hipGetErrorString(hipGetLastError()));
 }
 
+// The two passes of a vector-radix (2-D four-step) plan for 4096 x 4096 = (32 * 128)^2, each reading and writing
+// the plane ONCE (32 instead of 48 B/px per direction), as pure copies of 128-KiB tiles, one block of 1024 lanes
+// per CU, every load issued before the first store:
+//   MODE 1  the 32 x 32 points (128 a + r, 128 b + c), c in a run of 16 contiguous columns (128-byte runs,
+//           1-KiB apart within a row, rows 128 apart)
+//   MODE 2  a contiguous tile of 128 rows x 128 columns (1-KiB runs)
+template <int MODE>
+__global__ __launch_bounds__(1024) void tile2_k(const float* __restrict__ in, float* __restrict__ out, int total_tiles)
+{
+    extern __shared__ float occupancy_pad[];
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const unsigned tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    if ((int)tile >= total_tiles) return;
+    const i64 plane = tile / 1024;
+    const int tt = tile % 1024;
+    const int t = threadIdx.x;
+    i64 off[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int i = t + 1024 * k;                 // 16-byte access index within the tile
+        i64 row, col;                               // col in points
+        if (MODE == 1) {
+            const int r = tt / 8, c0 = (tt % 8) * 16;
+            const int run = i / 8, a = run / 32, bb = run % 32;
+            row = 128 * a + r; col = 128 * bb + c0 + (i % 8) * 2;
+        } else {
+            const int ty = tt / 32, tx = tt % 32;
+            row = 128 * ty + i / 64; col = 128 * tx + (i % 64) * 2;
+        }
+        off[k] = ((plane * 4096 + row) * 4096 + col) * 2;
+    }
+    f4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = *(const f4*)(in + off[k]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) *(f4*)(out + off[k]) = v[k] * 2.0f;
+}
+
+template <int MODE>
+void run_tile2(const char* name, const float* in, float* out, int planes, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tiles = planes * 1024;
+    hipFuncSetAttribute((const void*)tile2_k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 3; i++) tile2_k<MODE><<<tiles, 1024, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) tile2_k<MODE><<<tiles, 1024, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-60s lds %6d  %.3f ms  %.0f GB/s  (%s)\n", name, lds_bytes, ms, (double)planes * 4096 * 65536.0 / ms / 1e6,
+           hipGetErrorString(hipGetLastError()));
+}
+
 template <int V, bool COL, bool PERSIST>
 void run(const char* name, const float* in, float* out, int total_lines, int grid)
 {
@@ -138,6 +197,10 @@ int main()
     run_coltile<2, true>("whole-column tile, 2 columns (16-B runs), XCD remap", in, out, planes, 64 * 1024);
     run_coltile<2, false>("whole-column tile, 2 columns (16-B runs), no remap", in, out, planes, 64 * 1024);
     run_coltile<8, true>("whole-column tile, 8 columns (64-B runs; 256 KiB: unreal)", in, out, planes, 128 * 1024);
+    run_tile2<1>("2-pass plan, pass 1: 32x32 strided points x 128-B runs, 1 block/CU", in, out, planes, 128 * 1024);
+    run_tile2<2>("2-pass plan, pass 2: 128x128 contiguous tile, 1 block/CU", in, out, planes, 128 * 1024);
+    run_tile2<1>("2-pass plan, pass 1, 2 blocks/CU (unreal: 64 KiB of LDS)", in, out, planes, 64 * 1024);
+    run_tile2<2>("2-pass plan, pass 2, 2 blocks/CU (unreal: 64 KiB of LDS)", in, out, planes, 64 * 1024);
     run<2, false, false>("row b64 one block per line", in, out, total_lines, 0);
     run<4, false, false>("row b128 one block per line", in, out, total_lines, 0);
     run<2, true, false>("col b64 one block per line", in, out, total_lines, 0);

@@ -108,6 +108,60 @@ Scratch g_scratches[MAX_DEV];
 
 struct Rows { int lo, hi; };
 
+// One host thread moves about 20 GB/s between pageable and pinned memory; the PCIe link takes more than
+// twice that in each direction.  A CopyCrew is a few helper threads that each copy a slice of a staging
+// memcpy (the caller takes the first slice and returns when every slice is done).  The helpers live for
+// one host-tier call and poll with yield() between chunks, like the rest of this pipeline.
+class CopyCrew {
+public:
+    explicit CopyCrew(int helpers)
+    {
+        for (int i = 0; i < helpers; i++) th_.emplace_back([this, i] { work(i + 1); });
+    }
+    ~CopyCrew()
+    {
+        quit_.store(true, std::memory_order_release);
+        for (std::thread& t : th_) t.join();
+    }
+    CopyCrew(const CopyCrew&) = delete;
+    CopyCrew& operator=(const CopyCrew&) = delete;
+    void copy(void* dst, const void* src, size_t n)
+    {
+        const size_t parts = th_.size() + 1;
+        if (parts == 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
+        dst_ = (char*)dst; src_ = (const char*)src; n_ = n;
+        slice_ = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        memcpy(dst_, src_, std::min(slice_, n_));
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+
+private:
+    void work(int part)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t g;
+            while ((g = gen_.load(std::memory_order_acquire)) == seen) {
+                if (quit_.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            seen = g;
+            const size_t lo = std::min(n_, slice_ * (size_t)part), hi = std::min(n_, lo + slice_);
+            if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0};
+    std::atomic<bool> quit_{false};
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t n_ = 0, slice_ = 0;
+};
+
 int current_device(int* dev)
 {
     const hipError_t e = hipGetDevice(dev);
@@ -192,6 +246,9 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
     // The unloading side: chunk c leaves its slot's pinned buffer for `out` once the device is done
     // with it AND the main thread has staged chunk c+1 -- when `out` aliases `in`, chunk c+1's input
     // reaches into the rows chunk c overwrites (never further: a chunk is at least halo_sum rows).
+    // (helpers for the two staging memcpys: only for calls long enough to repay starting the threads)
+    const int copy_helpers = n_chunks >= 3 ? std::max(0, std::min(tuning().host_copy_threads, 8) - 1) : 0;
+    CopyCrew crew_in(copy_helpers), crew_out(copy_helpers);
     std::atomic<int> submitted{0}, unloaded{0};
     std::atomic<bool> abort_flag{false};
     hipError_t unload_err = hipSuccess;
@@ -205,7 +262,7 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
             const hipError_t err = hipEventSynchronize(s.done);
             if (err != hipSuccess) { unload_err = err; abort_flag.store(true, std::memory_order_release); return; }
             const Rows r = out_rows[c];
-            memcpy(out + (size_t)r.lo * pitch, s.pin_out, (size_t)(r.hi - r.lo) * pitch);
+            crew_out.copy(out + (size_t)r.lo * pitch, s.pin_out, (size_t)(r.hi - r.lo) * pitch);
             unloaded.store(c + 1, std::memory_order_release);
         }
     };
@@ -226,7 +283,7 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
             need[k] = Rows{std::max(0, need[k + 1].lo - halo), std::min(h, need[k + 1].hi + halo)};
         }
         out_rows[c] = need[n_ops];
-        memcpy(s.pin_in, in + (size_t)need[0].lo * pitch, (size_t)(need[0].hi - need[0].lo) * pitch);
+        crew_in.copy(s.pin_in, in + (size_t)need[0].lo * pitch, (size_t)(need[0].hi - need[0].lo) * pitch);
         e = hipMemcpyAsync(s.dev[0], s.pin_in, (size_t)(need[0].hi - need[0].lo) * pitch, hipMemcpyHostToDevice, s.stream);
         int cur = 0;
         for (int k = 0; k < n_ops && rc == MI_OK && e == hipSuccess; k++) {

@@ -29,6 +29,7 @@ struct Tuning {
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
     int mean_prefix = 1;          // MI_MEAN_PREFIX: mean 17x17..31x31 as a wave march on prefix sums (0: LDS tiles)
+    int host_copy_threads = 4;    // MI_HOST_COPY_THREADS: host threads per direction that stage a chunk between pageable and pinned memory
     int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
     int lds_pad_kib = 24;         // MI_LDS_PAD_KIB: extra LDS per block of the 3x3 march kernels (20 + 24 KiB: three blocks per CU, +2.5 %)
     int sep_lds_pad_kib = -1;     // MI_SEP_LDS_PAD_KIB: the same for the separable Gaussian (5x5) and mean kernels (-1: by kernel size)

@@ -14,10 +14,14 @@ SPEC = "gray,gauss:5:1.0,median:3,sobel"
 for w, h in ((3840, 2160), (8192, 8192), (16384, 16384)):
     img = ops.synth(2, w, h).cpu().numpy()
     out = np.empty_like(img)
-    ops.run_ops(out, img, w, h, SPEC)
+    # the first dozen calls on fresh host buffers run 30 % slower (the OS is still settling their pages:
+    # one call takes a hiccup, the following ones are fast), so the steady state is measured after 14 calls
+    for _ in range(14):
+        ops.run_ops(out, img, w, h, SPEC)
     for chunk in (None, 64, 256, 1024, h):
+        reps = 5
+        ops.run_ops(out, img, w, h, SPEC, chunk_rows=chunk)
         t0 = time.perf_counter()
-        reps = 3
         for _ in range(reps):
             ops.run_ops(out, img, w, h, SPEC, chunk_rows=chunk)
         dt = (time.perf_counter() - t0) / reps

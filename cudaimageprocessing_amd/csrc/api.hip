@@ -455,10 +455,11 @@ int mi_image_load(const uint8_t* bytes, uint8_t* pixels, size_t n_pixels)
     int rc = MI_OK;
     hipError_t e = hipMalloc(&d_a, n);
     if (e == hipSuccess) e = hipMalloc(&d_b, n);
-    if (e == hipSuccess) e = hipMemcpy(d_a, bytes, n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = launch_copy(d_a, d_b, n, nullptr);
-        if (rc == MI_OK) e = hipMemcpy(pixels, d_b, n, hipMemcpyDeviceToHost);
+        rc = host_upload(d_a, bytes, n);
+        if (rc == MI_OK) rc = launch_copy(d_a, d_b, n, nullptr);
+        if (rc == MI_OK) rc = hip_status(hipStreamSynchronize(nullptr), "mi_image_load");
+        if (rc == MI_OK) rc = host_download(pixels, d_b, n);
     }
     if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);
@@ -625,12 +626,12 @@ static int spectral_roundtrip(const uint8_t* in, uint8_t* out, int w, int h, int
     rc = host_scratch(img_bytes + work_bytes, &scratch);
     if (rc) return rc;
     char* d_img = (char*)scratch.ptr;
-    hipError_t e = hipMemcpy(d_img, in, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = spectral_roundtrip_dev(d_img, d_img, w, h, 1, rows, cols, edit, d_img + img_bytes, scratch.tables, nullptr);
-        if (rc == MI_OK) e = hipMemcpy(out, d_img, n * 4, hipMemcpyDeviceToHost);
-    }
-    return rc ? rc : hip_status(e, "spectral round trip");
+    rc = host_upload(d_img, in, n * 4);
+    if (rc == MI_OK) rc = spectral_roundtrip_dev(d_img, d_img, w, h, 1, rows, cols, edit, d_img + img_bytes, scratch.tables, nullptr);
+    // (the round trip runs on the null stream, which the staging streams do not wait for)
+    if (rc == MI_OK) rc = hip_status(hipStreamSynchronize(nullptr), "spectral round trip");
+    if (rc == MI_OK) rc = host_download(out, d_img, n * 4);
+    return rc;
 }
 
 int mi_fft_highpass_batch_workspace_bytes(int w, int h, int batch, size_t* bytes)

@@ -80,6 +80,9 @@ int host_batch_run(const uint8_t* in, uint8_t* out, int w, int h, int n_frames, 
 int host_strip_run(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, const int* devices,
                    int n_devices);
 int host_release();
+// Blocking whole-buffer copies between pageable host memory and the device, staged through pinned chunks.
+int host_upload(void* dev, const void* host, size_t bytes);
+int host_download(void* host, const void* dev, size_t bytes);
 // Device scratch of at least `bytes` for a blocking host-tier call, kept between calls (freed by
 // host_release).  The holder of `lock` owns the buffer: host-tier spectral calls serialise on it.
 struct HostScratch {

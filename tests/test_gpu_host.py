@@ -224,3 +224,23 @@ def test_multi_device_entry_points_of_the_c_abi(dev, golden):
         ops.strip_run_ops(np.zeros_like(buf), buf, spec, (0, 7))
     assert e.value.code == -1
 
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_staged_whole_image_copies(dev, threads):
+    """Host-tier calls that need the whole image on the device (imageFFTImageGenerate, imageLoadWrapper)
+    move images of 12 MiB or more through the pinned staging buffers in chunks: same bytes as the device
+    tier on the same image, for one staging thread and for several, sizes that are and are not a whole
+    number of chunks."""
+    with ops.tuning(MI_HOST_COPY_THREADS=threads, restore={"MI_HOST_COPY_THREADS": 4}):
+        for w, h in ((2048, 2048), (2050, 1777)):
+            img = S.pattern_image("natural", w, h, 9)
+            out = np.empty_like(img)
+            ops.imageFFTImageGenerate(out, img, w, h)
+            want = ops.fft_highpass(torch.from_numpy(img).to(dev)).cpu().numpy()
+            assert np.array_equal(out, want), (w, h)
+        n = 5_000_001                                            # 20 MB, not a multiple of anything
+        px = np.random.default_rng(3).integers(0, 256, (n, 4), dtype=np.uint8)
+        loaded = np.empty_like(px)
+        ops.imageLoadWrapper(px.reshape(-1), loaded, n)
+        assert np.array_equal(loaded, px)

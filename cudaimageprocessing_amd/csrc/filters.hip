@@ -928,18 +928,41 @@ __global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __re
 
     // the window keeps packed pixels (K x (4+2R) registers); a row is widened to floats when the
     // accumulation reaches it, so only one row of floats is live at a time
+    // 3x3 (the size the reference's demo asks for): rows in bursts through the LDS ring like the other 3x3
+    // kernels; the wider ones are bound by their k*k multiply-adds and keep the one-row register prefetch
+    typedef RowFeed<POL, (R == 1 ? MI_FEED_K : 0), 1> Feed;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
+    Feed feed(io, mch, ring, j.lane);
+    auto fed_row = [&](int c) {
+        const typename Feed::Row fr = feed.next(c, K - 1);
+        RowIn r;
+        r.p = fr.p;
+        r.h = u32x4{fr.h, 0u, 0u, 0u};
+        return r;
+    };
     u32 win[K][NC];
+    RowIn nxt{};
+    if constexpr (R == 1) {
+        feed.start(-R);
 #pragma unroll
-    for (int i = 0; i < K - 1; i++) columns(load_row(mch.row(i - R)), win[i]);
-    RowIn nxt = load_row(mch.row(R));
+        for (int i = 0; i < K - 1; i++) columns(fed_row(i), win[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) columns(load_row(mch.row(i - R)), win[i]);
+        nxt = load_row(mch.row(R));
+    }
     for (int base = 0; base < mch.n; base += K) {
 #pragma unroll
         for (int s = 0; s < K; s++) {
             const int i = base + s;
             if (i < mch.n) {
             const int y = mch.row(i);
-            columns(nxt, win[(K - 1 + s) % K]);      // row y+R; row y-R+t lives in slot (s+t)%K
-            nxt = load_row(mch.row(i + R + 1));
+            if constexpr (R == 1) {
+                columns(fed_row(i + K - 1), win[(K - 1 + s) % K]);
+            } else {
+                columns(nxt, win[(K - 1 + s) % K]);      // row y+R; row y-R+t lives in slot (s+t)%K
+                nxt = load_row(mch.row(i + R + 1));
+            }
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             float acc[4][3] = {};
 #pragma unroll
@@ -1694,7 +1717,7 @@ static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
 template <int R>
 static void launch_gauss_direct(int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const GaussW2& gw)
 {
-#define MI_L(P) gauss_direct_march_kernel<R, P><<<grid, 256, 0, s>>>(in, out, g, gw)
+#define MI_L(P) gauss_direct_march_kernel<R, P><<<grid, 256, (R == 1 ? lds_pad(1, g.total_waves) : 0), s>>>(in, out, g, gw)
     MI_POLICY_CASES(pol, MI_L)
 #undef MI_L
 }

@@ -14,6 +14,8 @@ F = {
     "gray": lambda: ops.grayscale(frames, out),
     "sobel": lambda: ops.sobel(frames, out),
     "mean3": lambda: ops.mean_blur(frames, 3, out),
+    "direct3": lambda: ops.gaussian_blur(frames, 3, 7.0, out, direct=True),
+    "direct5": lambda: ops.gaussian_blur(frames, 5, 1.0, out, direct=True),
     "median3": lambda: ops.median_blur(frames, 3, out),
     "gauss3": lambda: ops.gaussian_blur(frames, 3, 7.0, out),
     "gauss5": lambda: ops.gaussian_blur(frames, 5, 1.0, out),

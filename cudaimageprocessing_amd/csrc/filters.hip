@@ -601,22 +601,16 @@ __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32*
 
     // win[slot][v]: pair j (arrivals 2j, 2j+1) lives in slot j % NP
     u32 win[NP][12];
-    u32 even[12];                // the row sums of the last even arrival, until its partner arrives
-#pragma unroll
-    for (int e = 0; e < 12; e++) even[e] = 0u;
     auto arrive = [&](const RowIn& r, int a) __attribute__((always_inline)) {   // a = arrival index (static after unrolling)
         u32 h[12];
         irow(r, h);
         const int slot = (a / 2) % NP;
         if (a % 2 == 0) {
 #pragma unroll
-            for (int e = 0; e < 12; e++) {
-                even[e] = h[e];
-                win[slot][e] = __builtin_amdgcn_perm(0u, h[e], 0x0c0c0201u);          // (8.8 of this row, 0)
-            }
-        } else {
+            for (int e = 0; e < 12; e++) win[slot][e] = __builtin_amdgcn_perm(0u, h[e], 0x0c0c0201u);         // (8.8 of this row, 0)
+        } else {   // the partner of the even row already in the slot's low half
 #pragma unroll
-            for (int e = 0; e < 12; e++) win[slot][e] = __builtin_amdgcn_perm(h[e], even[e], 0x06050201u);   // (even row, odd row)
+            for (int e = 0; e < 12; e++) win[slot][e] = __builtin_amdgcn_perm(h[e], win[slot][e], 0x06050100u);   // (even row, odd row)
         }
     };
     // arrivals 0 .. 2R-1 = input rows row(-R) .. row(R-1); the first store follows arrival 2R

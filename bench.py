@@ -51,6 +51,17 @@ KERNELS = {"grayscale": "gray_kernel", "gaussian5": "gauss_sep_kernel<2>", "medi
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(frames=1, threads=1):
     """Oracle chain on `frames` synthetic 3840x2160 frames (checker code used as the baseline)."""
     from oracle import golden
@@ -387,7 +398,8 @@ def main():
             nthr = min(16, os.cpu_count() or 1)
             v2, dt2 = cpu_baseline(frames=16, threads=nthr)
             out["cpu_baseline_threads"] = {"value": v2, "unit": "MP/s", "cores": nthr, "kind": "port",
-                                           "sample": f"16 frames, row bands on {nthr} threads, {dt2:.1f} s"}
+                                           "sample": f"16 frames, row bands on {nthr} threads, {dt2:.1f} s",
+                                           "cpu_model": cpu_model(), "hardware_threads": os.cpu_count()}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

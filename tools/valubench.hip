@@ -76,6 +76,12 @@ __global__ __launch_bounds__(256) void bench(float* out, int iters, float seed)
                 h16x2 h = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(a[k].x, a[k].y));
                 h = h + __builtin_bit_cast(h16x2, a[k].y);
                 a[k].x = __builtin_bit_cast(float, h);
+            } else if (KIND == 17) {    // 2 v_fma_mix_f32 (f16 low / high half of src0 widened inside the fma)
+#if defined(__HIP_DEVICE_COMPILE__)
+                const u32 h = __builtin_bit_cast(u32, c.x) | 0x3c003c00u;
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(a[k].x) : "v"(h), "v"(m.x));
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[k].y) : "v"(h), "v"(m.y));
+#endif
             } else if (KIND == 16) {    // 2 v_floor_f32
                 a[k].x = __builtin_floorf(a[k].x + 0.5f);   // folds? keep the add out of the count if it stays
                 a[k].y = __builtin_floorf(a[k].y);
@@ -169,6 +175,7 @@ int main()
     run<14>("v_mad_u32_u24 x2 (+and)", 16, d);
     run<15>("cvt_pkrtz + pk_add_f16", 16, d);
     run<16>("v_floor_f32 x2 (+add)", 24, d);
+    run<17>("v_fma_mix_f32 x2", 16, d);
     run_lds(d);
     hipFree(d);
     return 0;

@@ -668,14 +668,18 @@ MI_DEV u32 mulhi_u24(u32 a, u32 b)
     return (u32)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32);
 }
 
+#ifndef MI_MEAN_WAVES
+#define MI_MEAN_WAVES 2
+#endif
 template <int R, int POL>
-__global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u32* __restrict__ in,
+__global__ __launch_bounds__(256, (R >= 5 ? MI_MEAN_WAVES : 1)) void mean_sep_kernel(const u32* __restrict__ in,
                                                        u32* __restrict__ out, const Geo g,
                                                        const u32 magic)
 {
     constexpr int K = 2 * R + 1;
     constexpr int HOPS = (R + 3) / 4;
     constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;   // pixels used of halo groups 1 and 2
+    constexpr int NH = 6;
     MI_MARCH_PROLOGUE();
 
     // input rows in bursts through a per-wave LDS ring (RowFeed, common.h) with the 4-pixel groups beside the strip
@@ -684,8 +688,9 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
     __shared__ __attribute__((aligned(1024))) unsigned char ring[Feed::BLOCK_BYTES];
     Feed feed(io, mch, ring, j.lane);
     const bool first_lane = j.lane == 0;
-    // h[2k] = (R,B) sums, h[2k+1] = (G,A) sums over columns k-R .. k+R, for the lane's pixel k
-    auto hrow = [&](const RowIn& r, u32 (&h)[8]) {
+    // h[k] = (R,B) sums over columns k-R .. k+R for the lane's pixel k; h[4], h[5] = the G sums of pixels (0,1), (2,3)
+    // (six registers a row: the alpha sums are never used, and the window is what limits the waves per SIMD)
+    auto hrow = [&](const RowIn& r, u32 (&h)[NH]) {
         u32 col[20];  // columns -8..11 at index c+8; unused entries are dead code
         const u32 p[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
         // halo group pixels: element i is the group's pixel 4-N+i in lane 0 (left of the strip) and
@@ -712,26 +717,28 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
         u32 lo[4 + 2 * R], hi[4 + 2 * R];
 #pragma unroll
         for (int i = 0; i < 4 + 2 * R; i++) unpack_px(col[8 - R + i], lo[i], hi[i]);
-        u32 sl = lo[0], sh = hi[0];
+        u32 sl = lo[0], sh = hi[0], gs[4];
 #pragma unroll
         for (int i = 1; i < K; i++) { sl = pk_add(sl, lo[i]); sh = pk_add(sh, hi[i]); }
-        h[0] = sl; h[1] = sh;
+        h[0] = sl; gs[0] = sh;
 #pragma unroll
         for (int k = 1; k < 4; k++) {
             sl = pk_add(pk_sub(sl, lo[k - 1]), lo[k + K - 1]);
             sh = pk_add(pk_sub(sh, hi[k - 1]), hi[k + K - 1]);
-            h[2 * k] = sl; h[2 * k + 1] = sh;
+            h[k] = sl; gs[k] = sh;
         }
+        h[4] = __builtin_amdgcn_perm(gs[1], gs[0], 0x05040100u);
+        h[5] = __builtin_amdgcn_perm(gs[3], gs[2], 0x05040100u);
     };
 
-    u32 win[K][8];
-    u32 cs[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    u32 win[K][NH];
+    u32 cs[NH] = {0u, 0u, 0u, 0u, 0u, 0u};
     feed.start(-R);
 #pragma unroll
     for (int i = 0; i < K - 1; i++) {
         hrow(feed.next(i, K - 1), win[i]);
 #pragma unroll
-        for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[i][e]);
+        for (int e = 0; e < NH; e++) cs[e] = pk_add(cs[e], win[i][e]);
     }
     constexpr int UNR = K;
     for (int base = 0; base < mch.n; base += UNR) {
@@ -743,21 +750,21 @@ __global__ __launch_bounds__(256, (R >= 5 ? 2 : 1)) void mean_sep_kernel(const u
             // rows y-R+t live in slot (s+t)%K; the newest one, y+R, replaces the row dropped last step
             hrow(feed.next(i + K - 1, K - 1), win[(K - 1 + s) % K]);
 #pragma unroll
-            for (int e = 0; e < 8; e++) cs[e] = pk_add(cs[e], win[(K - 1 + s) % K][e]);
+            for (int e = 0; e < NH; e++) cs[e] = pk_add(cs[e], win[(K - 1 + s) % K][e]);
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 // (s * magic) >> 24 as the high word of the 24-bit product (s << 8) * magic: s < 2^16 and
                 // magic < 2^24, and v_mul_hi_u32_u24 runs at full rate where a 32-bit multiply takes four slots
-                const u32 qr = mulhi_u24((cs[2 * k] & 0xFFFFu) << 8, magic);
-                const u32 qb = mulhi_u24((cs[2 * k] >> 16) << 8, magic);
-                const u32 qg = mulhi_u24((cs[2 * k + 1] & 0xFFFFu) << 8, magic);
+                const u32 qr = mulhi_u24((cs[k] & 0xFFFFu) << 8, magic);
+                const u32 qb = mulhi_u24((cs[k] >> 16) << 8, magic);
+                const u32 qg = mulhi_u24((k % 2 ? cs[4 + k / 2] >> 16 : cs[4 + k / 2] & 0xFFFFu) << 8, magic);
                 o[k] = (qr | (qg << 8) | (qb << 16) | 0xFF000000u) & xm[k] & rowm;
             }
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
 #pragma unroll
-            for (int e = 0; e < 8; e++) cs[e] = pk_sub(cs[e], win[s % K][e]);   // drop row y-R
+            for (int e = 0; e < NH; e++) cs[e] = pk_sub(cs[e], win[s % K][e]);   // drop row y-R
             }
         }
     }

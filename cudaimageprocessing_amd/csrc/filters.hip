@@ -813,12 +813,10 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
         hi_addr[k] = ((j.lane + (k + R) / 4) & 63) * 4;
         lo_addr[k] = ((j.lane - (R + 1 - k + 3) / 4) & 63) * 4;
     }
-    // h[2k] = (R,B), h[2k+1] = (G,A) sums over columns k-R .. k+R of one row, for the lane's pixel k
-    auto hrow = [&](u32x4 p, u32 (&h)[8]) {
-        const u32 px[4] = {p.x, p.y, p.z, p.w};
-        u32 pl[4], ph[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) unpack_px(px[k], pl[k], ph[k]);
+    // h[2k] = (R,B), h[2k+1] = (G,A) box sums over columns k-R .. k+R, for the lane's pixel k, of the packed
+    // 16-bit values pl / ph (one row's pixels, or the DIFFERENCE of the entering and the leaving row: prefix
+    // sums are linear and everything is modulo 2^16, so the halves of the result are then signed)
+    auto box = [&](u32 (&pl)[4], u32 (&ph)[4], u32 (&h)[8]) {
 #pragma unroll
         for (int k = 1; k < 4; k++) { pl[k] = pk_add(pl[k], pl[k - 1]); ph[k] = pk_add(ph[k], ph[k - 1]); }
         const u32 el = pk_sub(wave_scan_pk16(pl[3]), pl[3]), eh = pk_sub(wave_scan_pk16(ph[3]), ph[3]);
@@ -835,6 +833,25 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
             h[2 * k + 1] = pk_sub(ah, bh);
         }
     };
+    auto hrow = [&](u32x4 p, u32 (&h)[8]) {
+        const u32 px[4] = {p.x, p.y, p.z, p.w};
+        u32 pl[4], ph[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) unpack_px(px[k], pl[k], ph[k]);
+        box(pl, ph, h);
+    };
+    auto hrow_diff = [&](u32x4 pin, u32x4 pout, u32 (&h)[8]) {
+        const u32 pi[4] = {pin.x, pin.y, pin.z, pin.w}, po[4] = {pout.x, pout.y, pout.z, pout.w};
+        u32 pl[4], ph[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 il, ih, ol, oh;
+            unpack_px(pi[k], il, ih);
+            unpack_px(po[k], ol, oh);
+            pl[k] = pk_sub(il, ol); ph[k] = pk_sub(ih, oh);
+        }
+        box(pl, ph, h);
+    };
     // column sums: S[3k + c], c = R, G, B of pixel k
     u32 S[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     auto add_row = [&](const u32 (&h)[8]) {
@@ -843,13 +860,7 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
             S[3 * k] += h[2 * k] & 0xFFFFu; S[3 * k + 2] += h[2 * k] >> 16; S[3 * k + 1] += h[2 * k + 1] & 0xFFFFu;
         }
     };
-    auto sub_row = [&](const u32 (&h)[8]) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            S[3 * k] -= h[2 * k] & 0xFFFFu; S[3 * k + 2] -= h[2 * k] >> 16; S[3 * k + 1] -= h[2 * k + 1] & 0xFFFFu;
-        }
-    };
-    // rows row(-R) .. row(R-1) prime the sums; step i then adds row(i+R), stores, and drops row(i-R)
+    // rows row(-R) .. row(R-1) prime the sums
     {
         u32x4 nxt = io.load(mch.row(-R));
         for (int t = -R; t < R; t++) {
@@ -859,15 +870,27 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
             hrow(cur, h);
             add_row(h);
         }
-        u32x4 nxt_in = nxt, nxt_out = io.load(mch.row(-R));
+        // step 0 adds its entering row like the priming rows; step i > 0 adds (row(i+R) - row(i-R-1)) in ONE
+        // row pass: the box sums of the difference, sign-extended into the 32-bit column sums
+        u32x4 nxt_in = nxt, nxt_out = nxt;      // (step 0 has no leaving row)
         for (int i = 0; i < mch.n; i++) {
             const int y = mch.row(i);
             const u32x4 cin = nxt_in, cout = nxt_out;
             nxt_in = io.load(mch.row(i + 1 + R));
-            nxt_out = io.load(mch.row(i + 1 - R));
+            nxt_out = io.load(mch.row(i - R));  // leaves at step i + 1
             u32 h[8];
-            hrow(cin, h);
-            add_row(h);
+            if (i == 0) {
+                hrow(cin, h);
+                add_row(h);
+            } else {
+                hrow_diff(cin, cout, h);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    S[3 * k] += (u32)__builtin_amdgcn_sbfe((int)h[2 * k], 0, 16);
+                    S[3 * k + 2] += (u32)((int)h[2 * k] >> 16);
+                    S[3 * k + 1] += (u32)__builtin_amdgcn_sbfe((int)h[2 * k + 1], 0, 16);
+                }
+            }
             const u32 rowm = (y >= 1 && y <= g.H - 2) ? 0xFFFFFFFFu : 0u;
             u32 o[4];
 #pragma unroll
@@ -875,8 +898,6 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
                 o[k] = (__umulhi(S[3 * k], magic32) | (__umulhi(S[3 * k + 1], magic32) << 8) |
                         (__umulhi(S[3 * k + 2], magic32) << 16) | 0xFF000000u) & xm[k] & rowm;
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
-            hrow(cout, h);
-            sub_row(h);
         }
     }
 }

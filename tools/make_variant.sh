@@ -7,8 +7,8 @@ tag=$1
 root=$(cd "$(dirname "$0")/.." && pwd)
 lib=$root/cudaimageprocessing_amd/libmi_imagetools.so
 mkdir -p $root/tools/_var
-[ -f $lib ] && cp $lib /tmp/_keep_lib.so
+[ -f $lib ] && cp -p $lib /tmp/_keep_lib.so
 python3 $root/cudaimageprocessing_amd/build.py --force > /dev/null
 cp $lib $root/tools/_var/lib$tag.so
-[ -f /tmp/_keep_lib.so ] && cp /tmp/_keep_lib.so $lib && touch $lib
+[ -f /tmp/_keep_lib.so ] && cp -p /tmp/_keep_lib.so $lib   # (its old timestamp: the in-tree library stays "stale" if the sources changed)
 echo tools/_var/lib$tag.so

@@ -870,14 +870,13 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
             hrow(cur, h);
             add_row(h);
         }
-        // step 0 adds its entering row like the priming rows; step i > 0 adds (row(i+R) - row(i-R-1)) in ONE
-        // row pass: the box sums of the difference, sign-extended into the 32-bit column sums
-        u32x4 nxt_in = nxt, nxt_out = nxt;      // (step 0 has no leaving row)
-        for (int i = 0; i < mch.n; i++) {
+        // two steps' rows in flight: register sets A (even steps) and B (odd steps) are refilled right after
+        // use for the step after next, so no set is ever copied (the loop is unrolled by two)
+        auto step = [&](int i, u32x4& rin, u32x4& rout) {
             const int y = mch.row(i);
-            const u32x4 cin = nxt_in, cout = nxt_out;
-            nxt_in = io.load(mch.row(i + 1 + R));
-            nxt_out = io.load(mch.row(i - R));  // leaves at step i + 1
+            const u32x4 cin = rin, cout = rout;
+            rin = io.load(mch.row(i + 2 + R));          // enters at step i + 2
+            rout = io.load(mch.row(i + 1 - R));         // leaves at step i + 2
             u32 h[8];
             if (i == 0) {
                 hrow(cin, h);
@@ -898,6 +897,14 @@ __global__ __launch_bounds__(256) void mean_prefix_kernel(const u32* __restrict_
                 o[k] = (__umulhi(S[3 * k], magic32) | (__umulhi(S[3 * k + 1], magic32) << 8) |
                         (__umulhi(S[3 * k + 2], magic32) << 16) | 0xFF000000u) & xm[k] & rowm;
             io.store(y, u32x4{o[0], o[1], o[2], o[3]});
+        };
+        // step 0 adds its entering row like the priming rows; step i > 0 adds (row(i+R) - row(i-R-1)) in ONE
+        // row pass: the box sums of the difference, sign-extended into the 32-bit column sums
+        u32x4 in_a = nxt, out_a = nxt;                  // step 0: row(R); no leaving row
+        u32x4 in_b = io.load(mch.row(1 + R)), out_b = io.load(mch.row(-R));   // step 1
+        for (int i = 0; i < mch.n; i += 2) {
+            step(i, in_a, out_a);
+            if (i + 1 < mch.n) step(i + 1, in_b, out_b);
         }
     }
 }

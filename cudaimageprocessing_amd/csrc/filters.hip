@@ -1642,7 +1642,8 @@ static size_t lds_pad(int r, i64 total_waves)
     // the wider kernels are capped by their registers already
     int kib = r == 1 ? tuning().lds_pad_kib : tuning().sep_lds_pad_kib;
     if (r > 1 && kib < 0) kib = r == 2 ? 16 : r <= 4 ? 24 : 0;
-    return (size_t)std::max(0, std::min(kib, 40)) << 10;
+    // (static ring + padding stay within 64 KiB: 20 KiB for the 3x3 kernels, 30 KiB for the separable ones)
+    return (size_t)std::max(0, std::min(kib, r == 1 ? 40 : 32)) << 10;
 }
 static int grid_cap() { return 256 * 8; }  // 256 CUs x 8 blocks of 256 threads
 

@@ -309,6 +309,18 @@ def test_wide_mean_strips_tiles_and_oracle(dev, golden, k):
         assert torch.equal(out, whole[y0:y1]), (y0, y1)
 
 
+def test_wide_mean_odd_shapes_equal_the_tile_kernel(dev):
+    """Shapes around the prefix-sum march's strip width (224 pixels), unaligned widths (the 64-bit-address
+    policy), batches, a very wide image and images smaller than the kernel: same bytes as the LDS-tile
+    kernel, which the oracle tests pin."""
+    for (w, h, b) in ((32768, 256, 1), (8190, 1031, 1), (1000, 700, 3), (224, 40, 1), (225, 40, 2), (4, 4, 1), (3, 3, 1)):
+        img = ops.synth(7, w, h, batch=b) if b > 1 else ops.synth(7, w, h)
+        for k in (17, 31):
+            got = ops.mean_blur(img, k)
+            with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
+                assert torch.equal(got, ops.mean_blur(img, k)), (w, h, b, k)
+
+
 def test_large_batch_properties(dev):
     """Size-independent properties on a batch too large for the oracle: a batch result equals the
     same frames processed one by one, and a constant image stays constant inside the write set."""

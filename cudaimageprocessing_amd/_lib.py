@@ -65,6 +65,7 @@ SIGNATURES = {
     "mi_selftest": [],
     "mi_gaussian_kernel": [_i, _f, _vp],
     "mi_debug_set_tuning": [C.c_char_p, _i],
+    "mi_debug_get_tuning": [C.c_char_p, _vp],
     "mi_version": [],
     "mi_device_count": [],
 }

@@ -39,7 +39,7 @@ const Knob KNOBS[] = {
     {"MI_ROWS_PER_BAND", &Tuning::rows_per_band}, {"MI_CHAIN_ROWS_PER_BAND", &Tuning::chain_rows_per_band},
     {"MI_CHAIN_MARGIN", &Tuning::chain_margin}, {"MI_FFT_WAVES", &Tuning::fft_waves},
     {"MI_FFT_PERSISTENT", &Tuning::fft_persistent}, {"MI_FFT_PREFETCH", &Tuning::fft_prefetch},
-    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split},
+    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_TWOPASS_NT", &Tuning::fft_twopass_nt},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
     {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
@@ -66,6 +66,16 @@ bool set_tuning(const char* name, int value)
         if (name && strcmp(name, k.name) == 0) {
             // a plain int store: callers change knobs between launches, not concurrently with them
             tuning_rw().*(k.field) = value;
+            return true;
+        }
+    return false;
+}
+
+bool get_tuning(const char* name, int* value)
+{
+    for (const Knob& k : KNOBS)
+        if (name && strcmp(name, k.name) == 0) {
+            *value = tuning_rw().*(k.field);
             return true;
         }
     return false;
@@ -231,6 +241,12 @@ const char* mi_last_error(void) { return g_err; }
 int mi_debug_set_tuning(const char* name, int value)
 {
     return set_tuning(name, value) ? MI_OK : fail(MI_ERR_INVALID_ARG, "unknown tuning knob %s", name ? name : "(null)");
+}
+
+int mi_debug_get_tuning(const char* name, int* value)
+{
+    if (!value) return fail(MI_ERR_INVALID_ARG, "null pointer");
+    return get_tuning(name, value) ? MI_OK : fail(MI_ERR_INVALID_ARG, "unknown tuning knob %s", name ? name : "(null)");
 }
 
 int mi_device_count(void)

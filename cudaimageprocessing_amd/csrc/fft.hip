@@ -367,6 +367,12 @@ __global__ __launch_bounds__(256) void fft_small_kernel(const c2* __restrict__ i
     }
 }
 
+}  // namespace mi
+
+#include "fft_twopass.h"
+
+namespace mi {
+
 // ---------------------------------------------------------------- host side
 // The twiddle table of the current device is filled once, by the first FFT call on that device, and
 // that call blocks until the fill has completed before any stream is told the table exists: a first
@@ -502,10 +508,102 @@ static int launch_pass(int n, const c2* in, c2* out, const FftGeo& g, u32 bytes,
     }
 }
 
+// ---- the two-pass plan (fft_twopass.h)
+template <auto kernel>
+static int twopass_launch(int threads, size_t lds, const c2* in, c2* out, const TwoPassGeo& g, i64 ntiles, hipStream_t s)
+{
+    static PerDeviceAttr attr;          // per kernel (and device): the LDS attribute and the occupancy
+    int blocks_per_cu = 1;
+    const hipError_t attr_err = attr.get(&blocks_per_cu, [&](int* blocks) {
+        hipError_t e = hipSuccess;
+        if (lds > 64 * 1024) e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int n = 0;
+        if (e == hipSuccess && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) == hipSuccess && n > 0) *blocks = n;
+        return e;
+    });
+    if (attr_err != hipSuccess) return hip_status(attr_err, "hipFuncSetAttribute(max dynamic LDS)");
+    if (ntiles > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "fft launch too large");
+    kernel<<<(int)ntiles, threads, lds, s>>>(in, out, g);       // one tile per block
+    return hip_status(hipGetLastError(), "fft kernel launch");
+}
+
+template <int NC, int RX, int R2, bool DIF>
+static int twopass_rows(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
+{
+    constexpr size_t lds = ((size_t)2 * (NC + NC / 16) + Plan8<NC>::tw_total) * sizeof(c2);
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    if (g.nt_stores) return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, true>>(NC / 8, lds, in, out, g, (i64)g.planes * R2, s);
+    return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, false>>(NC / 8, lds, in, out, g, (i64)g.planes * R2, s);
+}
+
+template <int R2, int RX, int NC, bool DIF>
+static int twopass_cols(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
+{
+    constexpr int NCOL = 512 / (R2 / 32);
+    constexpr size_t lds = (size_t)(R2 + R2 / 32) * NCOL * 4 + (size_t)Plan32<R2>::tw_total * sizeof(c2);
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    if (g.nt_stores) return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, true>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
+    return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
+}
+
+// sizes the two-pass plan is built for
+static bool twopass_supported(int rows, int cols)
+{
+    return rows == 4096 && cols == 4096;
+}
+
+// order: 0 = cols pass then rows pass (DIT), 1 = rows pass then cols pass (DIF).  The cols pass is
+// out of place (src != dst), the rows pass works on its tile's own rows (src may equal dst).
+static int twopass_run(const c2* in, c2* mid, c2* out, int rows, int cols, int planes, int dir, int order, hipStream_t s)
+{
+    TwoPassGeo g;
+    g.planes = planes; g.plane_stride = (i64)rows * cols; g.inverse = dir > 0;
+    g.xcd_remap = tuning().fft_twopass_remap; g.nt_stores = tuning().fft_twopass_nt;
+    int rc;
+    if (order == 0) {
+        rc = twopass_cols<1024, 4, 4096, false>(in, mid, g, s);
+        if (rc == MI_OK) rc = twopass_rows<4096, 4, 1024, false>(mid, out, g, s);
+    } else {
+        rc = twopass_rows<4096, 4, 1024, true>(in, mid, g, s);
+        if (rc == MI_OK) rc = twopass_cols<1024, 4, 4096, true>(mid, out, g, s);
+    }
+    return rc;
+}
+
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s, void* tmp)
 {
     int rc = ensure_twiddles(s);
     if (rc) return rc;
+    if (tuning().fft_twopass && twopass_supported(rows, cols) && (in != out || tmp != nullptr)) {
+        const i64 plane = (i64)rows * cols;
+        const int order = tuning().fft_twopass == 2 ? 1 : 0;
+        if (in != out) {
+            // Both passes over up to MI_FFT_TWOPASS_GROUP planes at a time: a launch of fewer than a few
+            // thousand tiles pays for its ramp-up and tail (2 planes per launch: 4.0 ms per round trip of
+            // 16 planes; 8 or 16: 3.5 ms), which is worth more than finding the first pass's output
+            // in the Infinity Cache.
+            const int group = std::max(1, tuning().fft_twopass_group);
+            for (int b0 = 0; b0 < batch; b0 += group) {
+                const int nb = std::min(group, batch - b0);
+                const c2* pin = (const c2*)in + (i64)b0 * plane;
+                c2* pout = (c2*)out + (i64)b0 * plane;
+                // DIT: cols pass in -> out, rows pass in place;  DIF: rows pass in -> out, cols pass needs a third buffer
+                rc = order == 0 || !tmp ? twopass_run(pin, pout, pout, rows, cols, nb, dir, 0, s) : MI_OK;
+                if (order == 1 && tmp) {
+                    for (int b = 0; b < nb && rc == MI_OK; b++)
+                        rc = twopass_run(pin + b * plane, (c2*)tmp, pout + b * plane, rows, cols, 1, dir, 1, s);
+                }
+                if (rc) return rc;
+            }
+        } else {
+            for (int b = 0; b < batch; b++) {      // one plane of scratch: a plane at a time
+                c2* p = (c2*)out + (i64)b * plane;
+                rc = twopass_run(p, (c2*)tmp, p, rows, cols, 1, dir, 0, s);
+                if (rc) return rc;
+            }
+        }
+        return MI_OK;
+    }
     // Planes are transformed in groups that fit the 256 MiB Infinity Cache (all passes on the
     // same group back to back), so a pass finds the previous pass's output on die instead of
     // re-reading it from HBM.  MI_FFT_GROUP_MIB=0 makes every pass sweep the whole batch.

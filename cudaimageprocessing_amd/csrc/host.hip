@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -19,6 +21,90 @@
 namespace mi {
 
 namespace {
+
+// One host thread moves about 20 GB/s between pageable and pinned memory; the PCIe link takes more than
+// twice that in each direction.  A CopyCrew is a few helper threads that each copy a slice of a staging
+// memcpy (the caller takes the first slice and returns when every slice is done).  A pipe keeps its two
+// crews between calls.  An idle helper polls for about as long as a chunk takes to come round again
+// (the chunks of one call follow each other within a fraction of a millisecond) and then parks on a
+// condition variable: between calls, and while a device thread waits for the GPU, nothing spins.
+class CopyCrew {
+public:
+    explicit CopyCrew(int helpers)
+    {
+        for (int i = 0; i < helpers; i++) th_.emplace_back([this, i] { work(i + 1); });
+    }
+    ~CopyCrew()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            quit_.store(true, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    CopyCrew(const CopyCrew&) = delete;
+    CopyCrew& operator=(const CopyCrew&) = delete;
+    int helpers() const { return (int)th_.size(); }
+    void copy(void* dst, const void* src, size_t n)
+    {
+        const size_t parts = th_.size() + 1;
+        if (parts == 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
+        dst_ = (char*)dst; src_ = (const char*)src; n_ = n;
+        slice_ = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lock(mu_);      // a helper between its last poll and its wait sees the new job
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        if (parked_.load(std::memory_order_acquire) != 0) cv_.notify_all();
+        memcpy(dst_, src_, std::min(slice_, n_));
+        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+
+private:
+    void work(int part)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t g = seen;
+            for (int spin = 0; spin < 2000 && (g = gen_.load(std::memory_order_acquire)) == seen; spin++) {
+                if (quit_.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            if (g == seen) {
+                std::unique_lock<std::mutex> lock(mu_);
+                parked_.fetch_add(1, std::memory_order_acq_rel);
+                cv_.wait(lock, [&] { return gen_.load(std::memory_order_acquire) != seen || quit_.load(std::memory_order_acquire); });
+                parked_.fetch_sub(1, std::memory_order_acq_rel);
+                if (quit_.load(std::memory_order_acquire)) return;
+                g = gen_.load(std::memory_order_acquire);
+            }
+            seen = g;
+            const size_t lo = std::min(n_, slice_ * (size_t)part), hi = std::min(n_, lo + slice_);
+            if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0}, parked_{0};
+    std::atomic<bool> quit_{false};
+    char* dst_ = nullptr;
+    const char* src_ = nullptr;
+    size_t n_ = 0, slice_ = 0;
+};
+
+// Helper threads per crew: MI_HOST_COPY_THREADS - 1, shared out between the device threads when one call
+// drives several devices (run_on_devices sets the share), so that eight GPUs do not bring 56 helpers.
+thread_local int t_device_share = 1;
+int crew_helpers()
+{
+    const int threads = std::max(1, std::min(tuning().host_copy_threads, 8));
+    return std::max(0, threads / std::max(1, t_device_share) - 1);
+}
 
 struct Slot {
     void* pin_in = nullptr;
@@ -37,9 +123,19 @@ struct HostPipe {
     size_t cap_in = 0, cap_out = 0, cap_dev = 0;
     static constexpr int NSLOT = 3;
     Slot slot[NSLOT];
+    std::unique_ptr<CopyCrew> crew_in, crew_out;       // kept between calls
+
+    // the pipe's two crews with `helpers` helper threads each (called with mu held)
+    void crews(int helpers)
+    {
+        if (!crew_in || crew_in->helpers() != helpers) crew_in.reset(new CopyCrew(helpers));
+        if (!crew_out || crew_out->helpers() != helpers) crew_out.reset(new CopyCrew(helpers));
+    }
 
     void release()
     {
+        crew_in.reset();
+        crew_out.reset();
         for (Slot& s : slot) {
             if (s.pin_in) (void)hipHostFree(s.pin_in);
             if (s.pin_out) (void)hipHostFree(s.pin_out);
@@ -108,60 +204,6 @@ Scratch g_scratches[MAX_DEV];
 
 struct Rows { int lo, hi; };
 
-// One host thread moves about 20 GB/s between pageable and pinned memory; the PCIe link takes more than
-// twice that in each direction.  A CopyCrew is a few helper threads that each copy a slice of a staging
-// memcpy (the caller takes the first slice and returns when every slice is done).  The helpers live for
-// one host-tier call and poll with yield() between chunks, like the rest of this pipeline.
-class CopyCrew {
-public:
-    explicit CopyCrew(int helpers)
-    {
-        for (int i = 0; i < helpers; i++) th_.emplace_back([this, i] { work(i + 1); });
-    }
-    ~CopyCrew()
-    {
-        quit_.store(true, std::memory_order_release);
-        for (std::thread& t : th_) t.join();
-    }
-    CopyCrew(const CopyCrew&) = delete;
-    CopyCrew& operator=(const CopyCrew&) = delete;
-    void copy(void* dst, const void* src, size_t n)
-    {
-        const size_t parts = th_.size() + 1;
-        if (parts == 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
-        dst_ = (char*)dst; src_ = (const char*)src; n_ = n;
-        slice_ = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
-        pending_.store((int)th_.size(), std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_release);
-        memcpy(dst_, src_, std::min(slice_, n_));
-        while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
-    }
-
-private:
-    void work(int part)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            uint64_t g;
-            while ((g = gen_.load(std::memory_order_acquire)) == seen) {
-                if (quit_.load(std::memory_order_acquire)) return;
-                std::this_thread::yield();
-            }
-            seen = g;
-            const size_t lo = std::min(n_, slice_ * (size_t)part), hi = std::min(n_, lo + slice_);
-            if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
-            pending_.fetch_sub(1, std::memory_order_release);
-        }
-    }
-    std::vector<std::thread> th_;
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<int> pending_{0};
-    std::atomic<bool> quit_{false};
-    char* dst_ = nullptr;
-    const char* src_ = nullptr;
-    size_t n_ = 0, slice_ = 0;
-};
-
 int current_device(int* dev)
 {
     const hipError_t e = hipGetDevice(dev);
@@ -178,8 +220,10 @@ int host_release()
     int keep = -1;
     const bool have = hipGetDevice(&keep) == hipSuccess;
     for (int d = 0; d < MAX_DEV; d++) {
-        std::lock_guard<std::mutex> lock(g_pipes[d].mu);
-        std::lock_guard<std::mutex> lock2(g_scratches[d].mu);
+        // lock order everywhere: a device's scratch, then its pipe (the spectral round trips hold the
+        // scratch for the whole call and take the pipe for their staged copies)
+        std::lock_guard<std::mutex> lock(g_scratches[d].mu);
+        std::lock_guard<std::mutex> lock2(g_pipes[d].mu);
         const bool used = g_pipes[d].slot[0].stream || g_pipes[d].cap_dev || g_scratches[d].ptr;
         if (!used) continue;
         (void)hipSetDevice(d);
@@ -211,7 +255,7 @@ int host_scratch(size_t bytes, HostScratch* out)
 
 // Whole-buffer copies between pageable host memory and the device for the host-tier calls that need
 // the entire image on the device before they can start (the spectral round trips, the load repack):
-// staged through the pipe's pinned buffers in 8-MiB chunks -- CopyCrew fills or drains one chunk while
+// staged through the pipe's pinned buffers in 4-MiB chunks -- CopyCrew fills or drains one chunk while
 // the DMA engine moves its neighbours -- instead of one blocking hipMemcpy from pageable memory
 // (measured on a 4096 x 4096 image: 22 GB/s per direction that way).  Small copies stay a hipMemcpy.
 // The device's default stream must be idle for `dev` (callers use blocking calls around these).
@@ -230,7 +274,8 @@ int host_upload(void* dev, const void* host, size_t bytes)
     std::lock_guard<std::mutex> lock(pipe.mu);
     hipError_t e = pipe.reserve(STAGE_CHUNK, 0, 0);
     if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
-    CopyCrew crew(std::max(0, std::min(tuning().host_copy_threads, 8) - 1));
+    pipe.crews(crew_helpers());
+    CopyCrew& crew = *pipe.crew_in;
     int c = 0;
     for (size_t off = 0; off < bytes && e == hipSuccess; off += STAGE_CHUNK, c++) {
         Slot& s = pipe.slot[c % HostPipe::NSLOT];
@@ -258,7 +303,8 @@ int host_download(void* host, const void* dev, size_t bytes)
     std::lock_guard<std::mutex> lock(pipe.mu);
     hipError_t e = pipe.reserve(0, STAGE_CHUNK, 0);
     if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
-    CopyCrew crew(std::max(0, std::min(tuning().host_copy_threads, 8) - 1));
+    pipe.crews(crew_helpers());
+    CopyCrew& crew = *pipe.crew_out;
     const int n_chunks = (int)((bytes + STAGE_CHUNK - 1) / STAGE_CHUNK);
     auto issue = [&](int c) {
         Slot& s = pipe.slot[c % HostPipe::NSLOT];
@@ -320,9 +366,11 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
     // The unloading side: chunk c leaves its slot's pinned buffer for `out` once the device is done
     // with it AND the main thread has staged chunk c+1 -- when `out` aliases `in`, chunk c+1's input
     // reaches into the rows chunk c overwrites (never further: a chunk is at least halo_sum rows).
-    // (helpers for the two staging memcpys: only for calls long enough to repay starting the threads)
-    const int copy_helpers = n_chunks >= 3 ? std::max(0, std::min(tuning().host_copy_threads, 8) - 1) : 0;
-    CopyCrew crew_in(copy_helpers), crew_out(copy_helpers);
+    // (the pipe's crews; a call of one or two chunks copies on its own threads)
+    pipe.crews(crew_helpers());
+    CopyCrew solo_in(0), solo_out(0);
+    CopyCrew& crew_in = n_chunks >= 3 ? *pipe.crew_in : solo_in;
+    CopyCrew& crew_out = n_chunks >= 3 ? *pipe.crew_out : solo_out;
     std::atomic<int> submitted{0}, unloaded{0};
     std::atomic<bool> abort_flag{false};
     hipError_t unload_err = hipSuccess;
@@ -402,6 +450,7 @@ static int run_on_devices(const int* devices, int n_devices, Work work)
     std::vector<std::thread> threads;
     for (int i = 0; i < n_devices; i++)
         threads.emplace_back([&, i] {
+            t_device_share = n_devices;
             const hipError_t e = hipSetDevice(devices[i]);
             rcs[i] = e == hipSuccess ? work(i) : hip_status(e, "hipSetDevice");
             if (rcs[i] != MI_OK) msgs[i] = mi_last_error();      // the error text is per thread

@@ -26,6 +26,10 @@ struct Tuning {
     int fft_prefetch = 1;         // MI_FFT_PREFETCH
     int fft_group_mib = 300;      // MI_FFT_GROUP_MIB: planes per Infinity-Cache group
     int fft_split = 1;            // MI_FFT_SPLIT
+    int fft_twopass = 1;          // MI_FFT_TWOPASS: 4096x4096 planes in two passes per direction (fft_twopass.h); 2 = rows pass first where a third buffer allows
+    int fft_twopass_group = 8;    // MI_FFT_TWOPASS_GROUP: planes per launch of the two-pass kernels
+    int fft_twopass_remap = 1;    // MI_FFT_TWOPASS_REMAP: XCD-contiguous tiles
+    int fft_twopass_nt = 0;       // MI_FFT_TWOPASS_NT: non-temporal stores
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
     int mean_prefix = 1;          // MI_MEAN_PREFIX: mean 17x17..31x31 as a wave march on prefix sums (0: LDS tiles)
@@ -38,6 +42,7 @@ struct Tuning {
 const Tuning& tuning();
 // name: the environment variable's name; returns false for an unknown name
 bool set_tuning(const char* name, int value);
+bool get_tuning(const char* name, int* value);
 
 // One filter launch over a (strip of a) batch of frames; see Geo in common.h for the meaning
 // of the row arguments.  All pointers are device pointers.

@@ -128,21 +128,31 @@ def set_tuning(name, value):
     check(lib().mi_debug_set_tuning(str(name).encode(), int(value)))
 
 
+def get_tuning(name):
+    """The knob's current value (mi_debug_get_tuning): the default, the environment's, or an earlier set."""
+    import ctypes
+    v = ctypes.c_int(0)
+    check(lib().mi_debug_get_tuning(str(name).encode(), ctypes.byref(v)))
+    return int(v.value)
+
+
 class tuning:
-    """Context manager: `with ops.tuning(MI_ROWS_PER_BAND=8): ...`; `restore` gives the values to
-    put back afterwards (default: 0 = the library's own choice for the rows-per-band knobs)."""
+    """Context manager: `with ops.tuning(MI_ROWS_PER_BAND=8): ...` sets the knobs and puts back the
+    values they had on entry (so a knob set through the environment survives); `restore` overrides
+    what is put back for the knobs it names."""
 
     def __init__(self, restore=None, **knobs):
-        self.knobs, self.restore = knobs, restore or {}
+        self.knobs, self.restore, self.saved = knobs, restore or {}, {}
 
     def __enter__(self):
         for k, v in self.knobs.items():
+            self.saved[k] = get_tuning(k)
             set_tuning(k, v)
         return self
 
     def __exit__(self, *exc):
         for k in self.knobs:
-            set_tuning(k, self.restore.get(k, 0))
+            set_tuning(k, self.restore.get(k, self.saved[k]))
         return False
 
 

@@ -64,6 +64,8 @@ int mi_device_count(void);
  * one at run time (tests and tuning sweeps; not meant to race with launches on other threads).
  * Debug aid, not in the reference. */
 int mi_debug_set_tuning(const char *name, int value);
+/* The knob's current value (whatever set it: the default, the environment, an earlier set). */
+int mi_debug_get_tuning(const char *name, int *value);
 
 /* ---------------------------------------------------------------- device tier
  * All device-tier filters process `batch` frames of w x h pixels stored back to back. */

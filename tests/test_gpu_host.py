@@ -244,3 +244,42 @@ def test_staged_whole_image_copies(dev, threads):
         loaded = np.empty_like(px)
         ops.imageLoadWrapper(px.reshape(-1), loaded, n)
         assert np.array_equal(loaded, px)
+
+
+def test_host_release_concurrent_with_spectral_call(dev):
+    """mi_host_release takes a device's scratch mutex and then its pipe mutex -- the order the spectral
+    round trips take them in (scratch for the whole call, pipe for their staged copies of images of 12 MiB
+    or more).  With the order reversed the two deadlocked; run them against each other, under a watchdog."""
+    import threading
+    w = h = 2048
+    img = S.pattern_image("natural", w, h, 11)
+    want = np.empty_like(img)
+    ops.imageFFTImageGenerate(want, img, w, h)
+    stop = threading.Event()
+    errors = []
+
+    def releaser():
+        while not stop.is_set():
+            try:
+                _lib.check(_lib.lib().mi_host_release())
+            except Exception as exc:      # noqa: BLE001
+                errors.append(exc)
+                return
+
+    def caller():
+        try:
+            for _ in range(6):
+                out = np.empty_like(img)
+                ops.imageFFTImageGenerate(out, img, w, h)
+                assert np.array_equal(out, want)
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    r = threading.Thread(target=releaser, daemon=True)
+    c = threading.Thread(target=caller, daemon=True)
+    r.start(); c.start()
+    c.join(timeout=90)
+    stop.set()
+    r.join(timeout=30)
+    assert not c.is_alive() and not r.is_alive(), "deadlock between mi_host_release and mi_fft_highpass_u8x4"
+    assert not errors, errors

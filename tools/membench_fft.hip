@@ -159,6 +159,130 @@ void run_tile2(const char* name, const float* in, float* out, int planes, int ld
            hipGetErrorString(hipGetLastError()));
 }
 
+// The cols pass of the two-pass plan (csrc/fft_twopass.h) as a pure copy: a tile of NCOLS adjacent columns x
+// R2 = 16384 / NCOLS rows of one residue class (DIT: rows RX n2 + n1 in, rows R2 n1 + k2 out; DIF: rows
+// R2 k1 + n2 in, rows RX k2 + k1 out), 512 lanes x 32 points, every load issued before the first store,
+// persistent blocks (2 per CU) or one block per tile, tiles in launch order or remapped so that an XCD owns
+// a contiguous run of tiles, 8- or 16-byte accesses, optional non-temporal stores.
+template <int V, int NCOLS, bool DIF, int REMAP, bool NT>
+__global__ __launch_bounds__(512, 4) void cols2p_k(const float* __restrict__ in, float* __restrict__ out, int total_tiles)
+{
+    extern __shared__ float occupancy_pad[];
+    typedef float vec __attribute__((ext_vector_type(V)));
+    constexpr int R2 = 16384 / NCOLS, RX = 4096 / R2;
+    constexpr int LPR = NCOLS * 2 / V;              // lanes per run
+    constexpr int TT = 512 / LPR;                   // rows per access round
+    constexpr int PTS = R2 / TT;                    // accesses per lane
+    const int tid = threadIdx.x, cl = tid % LPR, t = tid / LPR;
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const unsigned logical = REMAP ? (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx : b;
+    const int per = (total_tiles + nblk - 1) / nblk;
+    for (int it = 0; it < per; it++) {
+        // REMAP 2: a block owns `per` consecutive tiles (an XCD: a contiguous range of the image)
+        const int tile = REMAP == 2 ? (int)logical * per + it : (int)logical + it * (int)nblk;
+        if (tile >= total_tiles) break;
+        constexpr int CG = 4096 / NCOLS;
+        const int cg = tile % CG, u = tile / CG, n1 = u % RX;
+        const i64 plane = u / RX;
+        const i64 in_base = DIF ? (i64)R2 * n1 : n1, out_base = DIF ? n1 : (i64)R2 * n1;
+        constexpr int in_stride = DIF ? 1 : RX, out_stride = DIF ? RX : 1;
+        vec v[PTS];
+#pragma unroll
+        for (int j = 0; j < PTS; j++) {
+            const i64 row = plane * 4096 + in_base + (i64)(t + TT * j) * in_stride;
+            v[j] = *(const vec*)(in + (row * 4096 + cg * NCOLS) * 2 + cl * V);
+        }
+#pragma unroll
+        for (int j = 0; j < PTS; j++) {
+            const i64 row = plane * 4096 + out_base + (i64)(t + TT * j) * out_stride;
+            vec* p = (vec*)(out + (row * 4096 + cg * NCOLS) * 2 + cl * V);
+            if (NT) __builtin_nontemporal_store(v[j] * 2.0f, p); else *p = v[j] * 2.0f;
+        }
+    }
+}
+
+template <int V, int NCOLS, bool DIF, int REMAP, bool NT>
+void run_cols2p(const char* name, const float* in, float* out, int planes, int grid, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tiles = planes * 1024;
+    const int g = grid > 0 ? grid : tiles;
+    hipFuncSetAttribute((const void*)cols2p_k<V, NCOLS, DIF, REMAP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 3; i++) cols2p_k<V, NCOLS, DIF, REMAP, NT><<<g, 512, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) cols2p_k<V, NCOLS, DIF, REMAP, NT><<<g, 512, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-64s grid %5d lds %6d  %.3f ms  %.0f GB/s  (%s)\n", name, g, lds_bytes, ms, (double)planes * 4096 * 65536.0 / ms / 1e6,
+           hipGetErrorString(hipGetLastError()));
+}
+
+typedef unsigned int u32b;
+typedef u32b u32x2bb __attribute__((ext_vector_type(2)));
+// the same with the library kernel's addressing: buffer descriptors, 32-bit lane offset + scalar offset, 8-byte accesses
+template <bool DIF, bool PROLOGUE, int GLOBAL = 0>
+__global__ __launch_bounds__(512, 4) void cols2p_buf_k(const float* __restrict__ in, float* __restrict__ out, int total_tiles, const float* __restrict__ table)
+{
+    extern __shared__ float lds_pad_[];
+    constexpr int R2 = 1024, RX = 4, NCOL = 16, T = 32;
+    const int tid = threadIdx.x, c = tid % NCOL, t = tid / NCOL;
+    float twr0 = 0.f, twr1 = 0.f;
+    if (PROLOGUE) { twr0 = table[tid * 16]; twr1 = table[(tid + 512) * 16]; }
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    if (tile >= total_tiles) return;
+    const int cg = tile & 255, u = tile >> 8, n1 = u & 3, plane = u >> 2;
+    constexpr u32b plane_bytes = 4096u * 4096u * 8u, row_bytes = 4096 * 8;
+    constexpr u32b in_stride = DIF ? 1u : RX, out_stride = DIF ? RX : 1u;
+    constexpr u32b in_step = T * in_stride * row_bytes, out_step = T * out_stride * row_bytes;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (i64)plane * 4096 * 8192), 0, (int)plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (i64)plane * 4096 * 8192), 0, (int)plane_bytes, 0x00020000);
+    const u32b in_base = DIF ? R2 * n1 : n1, out_base = DIF ? n1 : R2 * n1;
+    const u32b col_bytes = (u32b)(cg * NCOL + c) * 8u;
+    const u32b voff_in = (in_base + (u32b)t * in_stride) * row_bytes + col_bytes;
+    const u32b voff_out = (out_base + (u32b)t * out_stride) * row_bytes + col_bytes;
+    u32x2bb v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (GLOBAL & 1) v[j] = *(const u32x2bb*)((const char*)(in + (i64)plane * 4096 * 8192) + voff_in + j * in_step);
+        else v[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, voff_in, j * in_step, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (PROLOGUE) { lds_pad_[tid] = twr0; lds_pad_[tid + 512] = twr1; __syncthreads(); }
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (GLOBAL & 2) *(u32x2bb*)((char*)(out + (i64)plane * 4096 * 8192) + voff_out + j * out_step) = v[j];
+        else __builtin_amdgcn_raw_buffer_store_b64(v[j], rout, voff_out, j * out_step, 0);
+    }
+}
+
+template <bool DIF, bool PROLOGUE, int GLOBAL = 0>
+void run_cols2p_buf(const char* name, const float* in, float* out, int planes, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tiles = planes * 1024;
+    hipFuncSetAttribute((const void*)cols2p_buf_k<DIF, PROLOGUE, GLOBAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 3; i++) cols2p_buf_k<DIF, PROLOGUE, GLOBAL><<<tiles, 512, lds_bytes>>>(in, out, tiles, in);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) cols2p_buf_k<DIF, PROLOGUE, GLOBAL><<<tiles, 512, lds_bytes>>>(in, out, tiles, in);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-64s grid %5d lds %6d  %.3f ms  %.0f GB/s  (%s)\n", name, tiles, lds_bytes, ms, (double)planes * 4096 * 65536.0 / ms / 1e6,
+           hipGetErrorString(hipGetLastError()));
+}
+
 template <int V, bool COL, bool PERSIST>
 void run(const char* name, const float* in, float* out, int total_lines, int grid)
 {
@@ -179,12 +303,38 @@ void run(const char* name, const float* in, float* out, int total_lines, int gri
 
 int main()
 {
-    const int planes = 8;                       // 8 x 128 MiB in + out
+    const int planes = getenv("PLANES") ? atoi(getenv("PLANES")) : 8;                       // 8 x 128 MiB in + out
     const int total_lines = planes * 4096;
     float *in, *out;
     hipMalloc(&in, (size_t)total_lines * 32768);
     hipMalloc(&out, (size_t)total_lines * 32768);
     hipMemset(in, 0, (size_t)total_lines * 32768);
+    if (getenv("COLS2P")) {
+        const int L = 76 * 1024;
+        const int P = getenv("PLANES") ? atoi(getenv("PLANES")) : planes;
+        run_cols2p_buf<false, false>("buffer ops, b64 16 cols DIT, one block per tile, XCD-contiguous", in, out, P, L);
+        run_cols2p_buf<false, true>("buffer ops + table prologue + barrier, same", in, out, P, L);
+        run_cols2p_buf<false, true, 1>("global loads, buffer stores, same", in, out, P, L);
+        run_cols2p_buf<false, true, 2>("buffer loads, global stores, same", in, out, P, L);
+        run_cols2p_buf<false, true, 3>("global loads, global stores, same", in, out, P, L);
+        run_cols2p_buf<false, false, 3>("global loads, global stores, no prologue", in, out, P, L);
+        run_cols2p_buf<true, true>("buffer ops + table prologue + barrier, DIF", in, out, P, L);
+        run_cols2p<2, 16, false, 0, false>("b64 16 cols DIT persistent (the kernel's shape)", in, out, P, 512, L);
+        run_cols2p<2, 16, false, 1, false>("b64 16 cols DIT persistent, XCD-contiguous", in, out, P, 512, L);
+        run_cols2p<2, 16, false, 2, false>("b64 16 cols DIT persistent, block-contiguous tiles", in, out, P, 512, L);
+        run_cols2p<4, 16, false, 2, false>("b128 16 cols DIT persistent, block-contiguous tiles", in, out, P, 512, L);
+        run_cols2p<2, 16, false, 0, false>("b64 16 cols DIT, one block per tile", in, out, P, 0, L);
+        run_cols2p<2, 16, false, 1, false>("b64 16 cols DIT, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<2, 16, false, 1, true>("b64 16 cols DIT, one block per tile, XCD-contiguous, nt", in, out, P, 0, L);
+        run_cols2p<4, 16, false, 1, false>("b128 16 cols DIT, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<4, 16, false, 1, true>("b128 16 cols DIT, one block per tile, XCD-contiguous, nt", in, out, P, 0, L);
+        run_cols2p<4, 16, true, 1, false>("b128 16 cols DIF, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<2, 16, true, 1, false>("b64 16 cols DIF, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<4, 32, false, 1, false>("b128 32 cols x 512 DIT, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<2, 32, false, 1, false>("b64 32 cols x 512 DIT, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        run_cols2p<4, 64, false, 1, false>("b128 64 cols x 256 DIT, one block per tile, XCD-contiguous", in, out, P, 0, L);
+        return 0;
+    }
     for (int grid : {512, 768, 1024, 2048}) {
         run<2, false, true>("row b64 persistent", in, out, total_lines, grid);
         run<4, false, true>("row b128 persistent", in, out, total_lines, grid);

@@ -27,12 +27,21 @@ Extra objects in the line:
                 16 4096x4096 planes per GPU (weak scaling).
   cpu_baseline  the CPU oracle (a scalar C port of the reference's arithmetic) timed on this
                 host on a bounded sample of the same workload, rank 0 at N=1 only.
+  c1            BASELINE.json config 1 (rank 0 at N=1): the reference's sample image deer.jpeg decoded with
+                its stb_image, oracle grayscale + Gaussian 5x5 (sigma 1), PNG out -- ms per stage on one
+                host thread, and the same image through the library's host tier beside it.
+  checksum      CRC-32 of what the timed launches wrote (whole output for the headline; first, middle
+                and last frame or row band plus a device-side byte sum for the big legs), so the line can
+                be tied to the outputs the tests pin: tests/test_gpu_bench_checksums.py recomputes them
+                and holds them against tests/golden/bench_checksums.json and the oracle.
+  process_group backend and world size as torch.distributed reports them.
 """
 import argparse
 import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -49,6 +58,10 @@ KERNELS = {"grayscale": "gray_kernel", "gaussian5": "gauss_sep_kernel<2>", "medi
 # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) at the default workload
 # (batch 16): see profiles/.  None until measured for a kernel.
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
+# Share of a launch during which the vector ALUs were issuing (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, tools/
+# valu_roofline.sh): a kernel at 0.9 is bound by its instruction count, whatever its HBM fraction says.
+VALU_FILE = os.path.join(ROOT, "profiles", "valu_busy.json")
+VALU_BOUND = 0.85               # at or above this share of vector-issue time a kernel is labelled "valu"
 
 
 def cpu_model():
@@ -60,6 +73,17 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def host_threads():
+    """All hardware threads this process may use ('all hardware threads'): the affinity mask,
+    capped by the box's CPU share where the harness exports one (OMP_NUM_THREADS: os.cpu_count() shows the
+    whole machine there, of which a one-GPU box owns a fraction)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
 
 
 def cpu_baseline(frames=1, threads=1):
@@ -111,12 +135,91 @@ class Timer:
         return elapsed, call_ms
 
 
+_valu = None
+
+
+def valu_info(kernel):
+    global _valu
+    if _valu is None:
+        _valu = json.load(open(VALU_FILE)) if os.path.exists(VALU_FILE) else {"kernels": {}, "source": None}
+    k = _valu["kernels"].get(kernel)
+    return (k, _valu.get("source")) if k else (None, None)
+
+
 def roofline(kernel, alg_bytes, ms, traffic=None, **extra):
+    """`achieved`/`peak`/`frac` are always the HBM figures (algorithmic bytes over the launch time against
+    8 TB/s).  `bound` says what actually limits the kernel: "valu" when the profile in profiles/ shows its
+    vector ALUs issuing for >= 85 % of the launch (`valu_frac`, not measured by this run), else "hbm"."""
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    r = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    info, src = valu_info(kernel)
+    bound = "valu" if info and info["valu_busy"] >= VALU_BOUND else "hbm"
+    r = {"kernel": kernel, "bound": bound, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ms}
+    if info:
+        r["valu_frac"] = info["valu_busy"]
+        r["valu_source"] = f"not measured in this run: {src}"
     r.update(extra)
     return r
+
+
+def crc32_tensor(t):
+    """CRC-32 (zlib) of a device tensor's bytes."""
+    return zlib.crc32(t.contiguous().view(-1).cpu().numpy().tobytes()) & 0xffffffff
+
+
+def byte_sum(torch, t, chunk=1 << 30):
+    """Sum of all bytes of a uint8 device tensor, accumulated on the device in int64."""
+    flat = t.view(-1)
+    total = 0
+    for p in range(0, flat.numel(), chunk):
+        total += int(flat[p:p + chunk].sum(dtype=torch.int64).item())
+    return total
+
+
+def leg_c1(ops=None):
+    """C1: the reference's sample image deer.jpeg (2592x2000) decoded as the reference's loadImage
+    decodes it (stb_image v2.30, main.cpp:12-26), oracle grayscale + Gaussian 5x5 sigma 1 on one host
+    thread, PNG out (imageWriteWrapper writes a PNG whatever the name, imageTools.cu:152).  ms per stage,
+    MP/s, CRC-32 of the output pixels; beside it the same two filters through the library's host tier
+    (host pointers, PCIe both ways) with its output checked against the oracle's to +-1 (separable Gaussian)."""
+    import tempfile
+    import numpy as np
+    from oracle import golden
+    path = os.path.join(ROOT, "tests", "golden", "deer.jpeg")
+    t0 = time.perf_counter()
+    img = golden.stb_decode(path)
+    t1 = time.perf_counter()
+    h, w = img.shape[:2]
+    gray = golden.grayscale(img)
+    t2 = time.perf_counter()
+    blur = golden.gaussian(gray, 5, 1.0)
+    t3 = time.perf_counter()
+    out = {"workload": f"tests/golden/deer.jpeg {w}x{h}: stb_image decode -> grayscale -> Gaussian 5x5 sigma 1.0 -> PNG",
+           "cpu": {"kind": "port", "cores": 1, "decode_ms": (t1 - t0) * 1e3, "grayscale_ms": (t2 - t1) * 1e3,
+                   "gaussian5_ms": (t3 - t2) * 1e3, "filters_MP/s": w * h / 1e6 / (t3 - t1),
+                   "crc32_output": zlib.crc32(blur.tobytes()) & 0xffffffff}}
+    if ops is not None:
+        with tempfile.TemporaryDirectory() as tmp:
+            png = os.path.join(tmp, "deer_gray_blur.png")
+            t4 = time.perf_counter()
+            ops.imageWriteWrapper(png, blur, w, h)
+            out["cpu"]["png_write_ms"] = (time.perf_counter() - t4) * 1e3
+            out["cpu"]["png_bytes"] = os.path.getsize(png)
+        spec = ops.parse_ops("gray,gauss:5:1.0")
+        got = np.empty_like(img)
+        ops.run_ops(got, img, w, h, spec)                # first call: staging buffers are allocated
+        t5 = time.perf_counter()
+        for _ in range(5):
+            ops.run_ops(got, img, w, h, spec)
+        dt = (time.perf_counter() - t5) / 5
+        diff = int(np.abs(got.astype(np.int16) - blur.astype(np.int16)).max())
+        exact = np.empty_like(img)
+        ops.run_ops(exact, img, w, h, ops.parse_ops("gray,gauss_direct:5:1.0"))
+        out["gpu_host_tier"] = {"filters_ms": dt * 1e3, "filters_MP/s": w * h / 1e6 / dt,
+                                "note": "mi_run_ops_u8x4 on pageable host buffers, PCIe both ways included",
+                                "max_abs_diff_vs_cpu": diff, "crc32_output": zlib.crc32(got.tobytes()) & 0xffffffff,
+                                "direct_gaussian_bit_exact_vs_cpu": bool(np.array_equal(exact, blur))}
+    return out
 
 
 def leg_c3(torch, ops, timer, rank, world, dev, steps):
@@ -136,8 +239,12 @@ def leg_c3(torch, ops, timer, rank, world, dev, steps):
         ops.sobel(a, b)
     elapsed4, ms4 = timer.run(four, steps, 1)
     px = n * w * h
+    ops.fused_chain(frames, 1.0, a)
+    picks = sorted({0, n // 2, n - 1})
+    checksum = {"what": "fused-chain output of this rank's frames: CRC-32 of frames (global index) and the sum of all bytes",
+                "crc32_frames": {str(f0 + i): crc32_tensor(a[i]) for i in picks}, "byte_sum": byte_sum(torch, a)}
     return {"workload": f"{total} frames {w}x{h} RGBA u8, frames [{f0},{f1}) on rank 0, fused chain, one launch per step",
-            "scaling": "strong", "frames_per_gpu": n, "steps": steps,
+            "scaling": "strong", "frames_per_gpu": n, "steps": steps, "checksum": checksum,
             "value": total * w * h / 1e6 * steps / elapsed, "unit": "MP/s", "ms_per_step": elapsed / steps * 1e3,
             "roofline": roofline("chain_kernel", px * BYTES_PER_PIXEL, ms),
             "unfused": {"value": total * w * h / 1e6 * steps / elapsed4, "unit": "MP/s", "ms_per_step": elapsed4 / steps * 1e3,
@@ -187,11 +294,21 @@ def leg_c4(torch, ops, timer, rank, world, dev, steps):
         ms_halo = 0.0
         if world > 1:
             _, ms_halo = timer.run(exchange_only, steps, 1)
+        stage()
+        res = plan.strip(1)                       # this rank's rows of the stage's output
+        bands = sorted({0, (plan.n // 2) // 64 * 64, plan.n - 64})
+        checksum = {"what": "this rank's output rows: CRC-32 of 64-row bands (first global row) and the sum of all bytes",
+                    "crc32_bands": {str(plan.y0 + y): crc32_tensor(res[y:y + 64]) for y in bands}, "byte_sum": byte_sum(torch, res)}
+        # one GPU: the strip is one launch, the kernel's own time.  Several: the stage as timed -- halo exchange,
+        # interior launch, edge-band launches -- is what the configuration asks for.
+        roof_ms = ms if world > 1 else ms_compute
         out["per_filter"][name] = {
             "value": w * h / 1e6 * steps / elapsed, "unit": "MP/s", "ms_per_step": elapsed / steps * 1e3,
             "stage_ms_rank0": ms, "compute_only_ms_rank0": ms_compute, "halo_exchange_only_ms_rank0": ms_halo,
-            "roofline": roofline(kernel, plan.n * w * BYTES_PER_PIXEL, ms_compute,
-                                 note="this rank's strip as one launch; stage_ms adds the exchange and the edge-band launches")}
+            "checksum": checksum,
+            "roofline": roofline(kernel, plan.n * w * BYTES_PER_PIXEL, roof_ms,
+                                 note=("the whole stage on rank 0: halo exchange + interior launch + edge-band launches" if world > 1 else
+                                       "this rank's strip as one launch; stage_ms adds the exchange and the edge-band launches"))}
     return out
 
 
@@ -208,11 +325,25 @@ def leg_c5(torch, ops, timer, rank, world, dev, steps):
         ops.fft2d(f, inverse=True, out=y)
     elapsed, ms = timer.run(roundtrip, steps, 2)
     px = batch * n * n
-    return {"workload": f"fft2d + inverse fft2d, {batch} planes {n}x{n} complex fp32 per GPU, out of place",
+    # floating point: no byte checksum -- the round trip's error, Parseval and the DC coefficient instead
+    err = max(float(torch.linalg.vector_norm((y[b] / (n * n) - x[b]).to(torch.complex128)) /
+                    torch.linalg.vector_norm(x[b].to(torch.complex128))) for b in (0, batch - 1))
+    e_x = float((x[0].real.double() ** 2).sum())
+    e_f = float((f[0].real.double() ** 2 + f[0].imag.double() ** 2).sum())
+    checksum = {"what": "round trip of planes 0 and last: max rel-L2 of ifft(fft(x))/N - x; Parseval and DC of plane 0",
+                "roundtrip_rel_l2": err, "parseval_rel": abs(e_f - e_x * n * n) / (e_x * n * n),
+                "dc_rel": abs(complex(f[0, 0, 0].item()) - float(x[0].real.double().sum())) / float(x[0].real.double().sum())}
+    if err > 1e-5:
+        raise SystemExit(f"C5 round trip error {err} above 1e-5")
+    two_pass = ops.get_tuning("MI_FFT_TWOPASS") != 0
+    kernel = ("fft2p_cols_kernel + fft2p_rows_kernel (2 passes per direction)" if two_pass
+              else "fft_lines_kernel (3 line passes per direction)")
+    return {"workload": f"fft2d + inverse fft2d, {batch} planes {n}x{n} complex fp32 per GPU, out of place, natural order in and out",
             "scaling": "weak", "steps": steps, "value": world * px / 1e6 * steps / elapsed, "unit": "MP/s",
-            "ms_per_step": elapsed / steps * 1e3, "dtype": "f32",
-            "roofline": roofline("fft_lines_kernel (3 line passes per direction)", px * FFT_BYTES_PER_PIXEL, ms,
-                                 note="64 B/px algorithmic: 2 directions x 2 line passes x (8 B read + 8 B written)")}
+            "ms_per_step": elapsed / steps * 1e3, "dtype": "f32", "checksum": checksum,
+            "roofline": roofline(kernel, px * FFT_BYTES_PER_PIXEL, ms,
+                                 note="64 B/px algorithmic: 2 directions x 2 passes x (8 B read + 8 B written); avg_launch_ms is the "
+                                      "round trip (4 launches per plane group)")}
 
 
 def main():
@@ -328,6 +459,12 @@ def main():
         per_stage = [sum(ev4[k][i].elapsed_time(ev4[k][i + 1]) for k in range(args.steps)) / args.steps
                      for i in range(4)]
 
+    # what the timed launches wrote (bufs[3], both for the fused and the unfused step)
+    step()
+    torch.cuda.synchronize()
+    headline_checksum = {"what": "output of the timed step on rank 0 (all frames) and its first frame: CRC-32 (zlib)",
+                         "crc32": crc32_tensor(bufs[3]), "crc32_frame0": crc32_tensor(bufs[3][0]),
+                         "byte_sum": byte_sum(torch, bufs[3])}
     legs = {}
     del bufs[:3]
     for leg in [s for s in args.legs.split(",") if s]:
@@ -386,6 +523,9 @@ def main():
                                    f"batch {B} frames per GPU, device-resident, {desc}",
                        "frames_per_gpu": B, "width": W, "height": H, "sharding": f"batch x{world}"},
             "roofline": roofline(kname, alg_bytes, kms, traffic.get(kname), traffic_source=traffic_source),
+            "checksum": headline_checksum,
+            "process_group": {"backend": (dist.get_backend() if dist is not None else None),
+                              "world_size": (dist.get_world_size() if dist is not None else 1)},
             "unfused": {"value": B * W * H / 1e6 * args.steps / unfused_elapsed, "unit": "MP/s (rank 0)",
                         "ms_per_step": unfused_elapsed / args.steps * 1e3, "per_filter": per_filter},
         }
@@ -395,11 +535,13 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "MP/s", "cores": 1, "kind": "port",
                                    "sample": f"the same 4-stage chain on 8 synthetic {W}x{H} frames, "
                                              f"oracle/golden.c single thread, {dt:.1f} s"}
-            nthr = min(16, os.cpu_count() or 1)
-            v2, dt2 = cpu_baseline(frames=16, threads=nthr)
+            nthr = host_threads()
+            nfr = max(16, min(256, nthr))
+            v2, dt2 = cpu_baseline(frames=nfr, threads=nthr)
             out["cpu_baseline_threads"] = {"value": v2, "unit": "MP/s", "cores": nthr, "kind": "port",
-                                           "sample": f"16 frames, row bands on {nthr} threads, {dt2:.1f} s",
+                                           "sample": f"{nfr} frames, row bands on {nthr} threads, {dt2:.1f} s",
                                            "cpu_model": cpu_model(), "hardware_threads": os.cpu_count()}
+            out["c1"] = leg_c1(ops)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

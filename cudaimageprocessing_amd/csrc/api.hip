@@ -407,11 +407,15 @@ int mi_fft2d_c2c_f32_ws_dev(const void* d_in, void* d_out, int rows, int cols, i
     int rc = mi_fft2d_workspace_bytes(rows, cols, &need);
     if (rc) return rc;
     const bool pow2 = (rows & (rows - 1)) == 0 && (cols & (cols - 1)) == 0;
-    if (pow2 && (!d_workspace || workspace_bytes < need || d_in != d_out)) {
-        // powers of two: the workspace is optional (it only speeds up tall planes in place)
+    if (pow2) {
+        // powers of two: the workspace is optional (one plane of it lets a tall plane be transformed in
+        // place at full speed, and lets the two-pass plan run its rows pass first when asked to)
         const size_t bytes = (size_t)rows * cols * 8 * batch;
         if (d_in != d_out && overlap(d_in, bytes, d_out, bytes)) return fail(MI_ERR_OVERLAP, "partially overlapping buffers");
-        return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream);
+        void* tmp = (d_workspace && need && workspace_bytes >= need) ? d_workspace : nullptr;
+        if (tmp && (overlap(tmp, need, d_in, bytes) || overlap(tmp, need, d_out, bytes)))
+            return fail(MI_ERR_OVERLAP, "workspace overlaps the data");
+        return launch_fft2d(d_in, d_out, rows, cols, batch, direction, (hipStream_t)stream, tmp);
     }
     if (need && (!d_workspace || workspace_bytes < need))
         return fail(MI_ERR_INVALID_ARG, "fft2d %dx%d needs a workspace of %zu bytes (got %zu)", rows, cols, need, d_workspace ? workspace_bytes : (size_t)0);

@@ -23,6 +23,37 @@ def build(force=False):
     return _SO
 
 
+_STB_SO = os.path.join(_HERE, "libstbdecode.so")
+_stb = None
+
+
+def build_stb(force=False):
+    src = os.path.join(_HERE, "stb_decode.c")
+    if force or not os.path.exists(_STB_SO) or os.path.getmtime(_STB_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libstbdecode.so"], stdout=subprocess.DEVNULL)
+    return _STB_SO
+
+
+def stb_decode(path):
+    """(H, W, 4) uint8 RGBA of an image file, decoded as the reference's loadImage decodes it
+    (stbi_load(..., STBI_rgb_alpha), main.cpp:14) with the same stb_image v2.30."""
+    global _stb
+    if _stb is None:
+        _stb = C.CDLL(build_stb())
+        _stb.gold_stb_load_rgba.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _stb.gold_stb_load_rgba.restype = C.c_void_p
+        _stb.gold_stb_free.argtypes = [C.c_void_p]
+        _stb.gold_stb_free.restype = None
+    w, h = C.c_int(0), C.c_int(0)
+    p = _stb.gold_stb_load_rgba(os.fsencode(path), C.byref(w), C.byref(h))
+    if not p:
+        raise OSError(f"stb_image cannot decode {path}")
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 4)).copy()
+    finally:
+        _stb.gold_stb_free(p)
+
+
 def _load():
     if not os.path.exists(_SO):
         build()

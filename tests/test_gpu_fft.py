@@ -233,6 +233,46 @@ def test_fft2d_4096_batch16_full_spectrum_against_double_precision(dev):
     assert worst_f <= REL_L2 and worst_b <= REL_L2, (worst_f, worst_b)
 
 
+def test_fft2d_4096_two_pass_plan_orders_groups_and_in_place(dev):
+    """4096 x 4096 planes take the two-pass plan (csrc/fft_twopass.h): cols pass then rows pass (DIT), or rows
+    pass then cols pass (DIF, MI_FFT_TWOPASS=2 with a workspace).  Both orders, forward and inverse, out of
+    place and in place through a workspace, a batch that does not fill its last launch group, against
+    numpy.fft in double precision and against the three-pass plan (MI_FFT_TWOPASS=0) it replaces."""
+    n = 4096
+    x0 = rand_plane(n, n, 77)
+    ref_f = np.fft.fft2(x0.astype(np.complex128))
+    ref_i = np.fft.ifft2(x0.astype(np.complex128)) * float(n * n)
+    xd = torch.from_numpy(x0).to(dev)
+    ws = torch.empty(ops.fft2d_workspace_bytes(n, n), dtype=torch.uint8, device=dev)
+    assert ws.numel() >= n * n * 8
+    assert ops.get_tuning("MI_FFT_TWOPASS") == 1
+    results = {}
+    for mode in (0, 1, 2):
+        with ops.tuning(MI_FFT_TWOPASS=mode):
+            f = ops.fft2d(xd)
+            assert rel_l2(f.cpu().numpy(), ref_f) <= REL_L2, mode
+            assert rel_l2(ops.fft2d(xd, inverse=True).cpu().numpy(), ref_i) <= REL_L2, mode
+            y = xd.clone()
+            ops.fft2d(y, out=y, workspace=ws)                       # in place: one plane of scratch
+            assert rel_l2(y.cpu().numpy(), ref_f) <= REL_L2, mode
+            # out of place WITH a workspace: mode 2 runs the rows pass first (DIF order)
+            g = torch.empty_like(xd)
+            _lib.check(_lib.lib().mi_fft2d_c2c_f32_ws_dev(xd.data_ptr(), g.data_ptr(), n, n, 1, _lib.FFT_FORWARD,
+                                                          ws.data_ptr(), ws.numel(), None))
+            torch.cuda.synchronize()
+            results[mode] = (f, y, g)
+    # the two orders are the same arithmetic in a different sequence: close, not necessarily equal
+    assert rel_l2(results[2][2].cpu().numpy(), ref_f) <= REL_L2
+    assert torch.equal(results[1][0], results[1][1])                # in place == out of place (same kernels)
+    # a batch of 3 planes in launch groups of 2 (the last group is partial)
+    xb = torch.stack([xd, xd.flip(0), xd * 0.5])
+    with ops.tuning(MI_FFT_TWOPASS_GROUP=2):
+        fb = ops.fft2d(xb)
+    assert torch.equal(fb[0], results[1][0])
+    assert torch.equal(fb[1], ops.fft2d(xb[1].contiguous()))
+    assert torch.equal(fb[2], ops.fft2d(xb[2].contiguous()))
+
+
 def test_pointwise_stages_match_oracle(dev, golden):
     img = S.synth_image(4, 96, 64)
     planes = ops.u8_to_complex(torch.from_numpy(img).to(dev))

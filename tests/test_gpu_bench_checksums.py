@@ -41,6 +41,14 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff
 
 
+def oracle_chain_crc(golden, img, img_dev):
+    gray = golden.grayscale(img, threads=8)
+    assert np.array_equal(ops.grayscale(img_dev).cpu().numpy(), gray)
+    blur_dev = ops.gaussian_blur(torch.from_numpy(gray).to(img_dev.device), 5, 1.0).cpu().numpy()
+    assert np.abs(blur_dev.astype(np.int16) - golden.gaussian(gray, 5, 1.0, threads=8).astype(np.int16)).max() <= 1
+    return crc(golden.sobel(golden.medianblur(blur_dev, 3, threads=8), threads=8))
+
+
 def test_c2_headline_output(want, timer, golden):
     _, dev = timer
     frames = ops.synth(2, bench.W, bench.H, batch=16, device=dev)
@@ -48,9 +56,11 @@ def test_c2_headline_output(want, timer, golden):
     assert bench.crc32_tensor(out) == want["c2"]["crc32"]
     assert bench.crc32_tensor(out[0]) == want["c2"]["crc32_frame0"]
     assert bench.byte_sum(torch, out) == want["c2"]["byte_sum"]
-    # the same constant from the oracle: frame 0 of the synthetic stream through the CPU chain
-    ref = golden.chain(golden.synth(2, bench.W, bench.H), threads=8)
-    assert crc(ref) == want["c2"]["crc32_frame0"]
+    # The same constant from the oracle, frame 0 of the synthetic stream.  The chain's Gaussian stage is the
+    # separable one (+-1 against the reference's direct sum by contract), so the tie goes through that stage's
+    # device output: oracle gray == device gray, device Gaussian within 1 of the oracle's, and from there the
+    # oracle's median and Sobel give the constant bit for bit.
+    assert oracle_chain_crc(golden, golden.synth(2, bench.W, bench.H), frames[0]) == want["c2"]["crc32_frame0"]
 
 
 def test_c3_leg_output(want, timer, golden):
@@ -61,8 +71,8 @@ def test_c3_leg_output(want, timer, golden):
     assert got["byte_sum"] == want["c3"]["byte_sum"]
     w, h = 1920, 1080
     for f, c in want["c3"]["crc32_frames"].items():
-        ref = golden.chain(golden.synth(1000, w, h, first_idx=int(f) * w * h), threads=8)
-        assert crc(ref) == c, f
+        img = golden.synth(1000, w, h, first_idx=int(f) * w * h)
+        assert oracle_chain_crc(golden, img, torch.from_numpy(img).to(dev)) == c, f
 
 
 def test_c4_leg_output(want, timer, golden):

@@ -61,6 +61,26 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+GUARD_LIB_PATH = os.path.join(_PKG, "libmi_imagetools_guard.so")
+
+
+def build_guard(force=False):
+    """libmi_imagetools_guard.so: the same library with filters.hip compiled -DMI_ROWFEED_FULL_WAIT=1 (every
+    hand-counted s_waitcnt in RowFeed replaced by vmcnt(0), common.h).  Test infrastructure: tests/test_gpu_guard.py
+    holds the product library to it bit for bit.  Only filters.hip uses RowFeed; the other objects are shared."""
+    lib = build()
+    src = os.path.join(_CSRC, "filters.hip")
+    deps = [src, os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "internal.h"), os.path.join(_CSRC, "median5_network.h"), lib]
+    if not force and os.path.exists(GUARD_LIB_PATH) and all(os.path.getmtime(GUARD_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return GUARD_LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    obj = os.path.join(_CSRC, "filters_guard.o")
+    subprocess.check_call([hipcc] + FLAGS + ["-DMI_ROWFEED_FULL_WAIT=1", "-c", src, "-o", obj])
+    objs = [obj if s == "filters.hip" else os.path.join(_CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", GUARD_LIB_PATH] + objs + ["-lz", "-pthread"])
+    return GUARD_LIB_PATH
+
+
 DEMO_SRC = os.path.normpath(os.path.join(_PKG, "..", "demo", "imgtool.cpp"))
 DEMO_BIN = os.path.normpath(os.path.join(_PKG, "..", "demo", "imgtool"))
 
@@ -82,3 +102,4 @@ def build_demo(force=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
     print(build_demo(force="--force" in sys.argv))
+    print(build_guard(force="--force" in sys.argv))

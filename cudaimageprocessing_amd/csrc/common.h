@@ -322,6 +322,14 @@ struct RowIO<1> {
 // Usage: feed.start(first_row_index) once, then feed.next(c, prime) for consumption c = 0, 1, 2, ...
 // (rows first, first+1, ... in marching order); `prime` = consumptions before the kernel's first store.
 // For POL 0 the feed degenerates to the one-row-ahead register prefetch.
+// MI_ROWFEED_FULL_WAIT=1 (the guard build, libmi_imagetools_guard.so) replaces every counted wait by
+// s_waitcnt vmcnt(0).  The counts above are only right while a step issues exactly the memory operations
+// this comment lists; tests/test_gpu_guard.py compares the product library with the guard build bit for
+// bit, so a compiler that adds or drops one (a spill, an elided store) is caught as a difference.
+#ifndef MI_ROWFEED_FULL_WAIT
+#define MI_ROWFEED_FULL_WAIT 0
+#endif
+
 template <int POL, int K_, int HALO>
 struct RowFeed {
     static constexpr bool HALO1 = HALO != 0;
@@ -402,7 +410,9 @@ struct RowFeed {
                 const int half = slot >= K ? 0 : K;      // the half of the ring the last K consumptions have read
 #pragma unroll
                 for (int p = 0; p < K; p++) request(mch.row(first + c + K + p), half + p);
-                if (c < prime + K) wait_vm<L>(); else wait_vm<K + L>();
+                if (MI_ROWFEED_FULL_WAIT) wait_vm<0>();
+                else if (c < prime + K) wait_vm<L>();
+                else wait_vm<K + L>();
             }
             const unsigned char* sl = ring + slot * SLOT_BYTES;
             r.p = *reinterpret_cast<const u32x4*>(sl + 16 * lane);

@@ -90,6 +90,49 @@ __global__ __launch_bounds__(256) void march_burst(const u32* __restrict__ in, u
     }
 }
 
+// Row-synchronous form (round 3): one workgroup of NW waves spans the WHOLE image row (NW x 1 KiB = the row:
+// 3840 px = 15 waves), owns a band of rows, and issues its bursts in lockstep -- one s_barrier per burst -- so
+// that a burst of K rows is one contiguous run of K x W x 4 bytes (full-width rows are adjacent in memory)
+// instead of NW 1-KiB pieces at independent phases.  Blocks are dealt to XCDs so that neighbouring bands share one.
+template <int K, int NW, int SYNC>
+__global__ __launch_bounds__(64 * NW) void march_rowsync(const u32* __restrict__ in, u32* __restrict__ out, const Geo g, int ov)
+{
+    extern __shared__ u32 occupancy_pad[];
+    const u32 nblk = gridDim.x, b = blockIdx.x;
+    const u32 q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const u32 logical = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx : b;
+    WaveJob j;
+    j.strip = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    j.band = logical % g.bands;
+    j.frame = logical / g.bands;
+    j.lane = threadIdx.x & 63;
+    j.valid = true;
+    const March mch = make_march(g, j);
+    const RowIO<1> io(in, out, g, j, mch, j.strip * 256, 0);
+    auto load = [&](int row) { return __builtin_amdgcn_raw_buffer_load_b128(io.rin, (row - io.row0) * io.pitch + io.in_off, 0, 0); };
+    auto store = [&](int y, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, io.rout, (u32)((y - io.ylo) * io.pitch) + io.out_off, 0, 2); };
+    u32x4 q[2][K];
+#pragma unroll
+    for (int p = 0; p < K; p++) q[0][p] = load(mch.row(p - ov));
+    const int steps = mch.n + ov;          // block-uniform
+    for (int base = 0; base < steps; base += 2 * K) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int b0 = base + h * K;
+            if (b0 < steps) {
+                if (SYNC) __syncthreads();
+#pragma unroll
+                for (int p = 0; p < K; p++) q[h ^ 1][p] = load(mch.row(b0 + K + p - ov));
+#pragma unroll
+                for (int p = 0; p < K; p++) {
+                    const u32x4 v = q[h][p] ^ u32x4{1u, 2u, 3u, 4u};
+                    if (b0 + p < steps) store(mch.row(b0 + p - ov), v);
+                }
+            }
+        }
+    }
+}
+
 struct Cfg { int pf, mrg, ldaux, staux, rpb, ov, blocks_per_cu, remap, vec, W, H, B; };
 
 template <int PF, int MRG, int LDAUX, int STAUX, int VEC>
@@ -160,8 +203,44 @@ static float run_burst(const u32* in, u32* out, Geo g, const Cfg& c, int reps)
     return ms / reps;
 }
 
+template <int K, int NW, int SYNC>
+static float run_rowsync(const u32* in, u32* out, Geo g, const Cfg& c, int reps)
+{
+    g.W = c.W; g.H = c.H; g.batch = c.B; g.y_end = c.H;
+    g.N = (i64)c.W * c.H; g.in_hi = g.N; g.in_frame_stride = g.N; g.out_frame_stride = g.N;
+    if (c.W != NW * 256) return -1.f;
+    g.strips = NW;
+    g.rows_per_band = c.rpb;
+    g.bands = (g.H + c.rpb - 1) / c.rpb;
+    g.total_waves = g.batch * g.bands * g.strips;
+    g.xcd_remap = c.remap;
+    const int grid = g.batch * g.bands;
+    const size_t lds = c.blocks_per_cu >= 8 ? 0 : (size_t)(160 * 1024 / c.blocks_per_cu) & ~(size_t)255;
+    CK(hipFuncSetAttribute((const void*)march_rowsync<K, NW, SYNC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 10; i++) march_rowsync<K, NW, SYNC><<<grid, 64 * NW, lds>>>(in, out, g, c.ov);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; i++) march_rowsync<K, NW, SYNC><<<grid, 64 * NW, lds>>>(in, out, g, c.ov);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms / reps;
+}
+
 static float dispatch(const u32* in, u32* out, const Geo& g, const Cfg& c, int reps)
 {
+    // vec 20 / 21: the row-synchronous form (pf = burst size), with / without the barrier; W = 3840 (15 waves) or 4096 (16)
+    if (c.vec == 20 || c.vec == 21) {
+#define RC(KK) if (c.pf == KK) { if (c.W == 3840) return c.vec == 20 ? run_rowsync<KK, 15, 1>(in, out, g, c, reps) : run_rowsync<KK, 15, 0>(in, out, g, c, reps); \
+                                 if (c.W == 4096) return c.vec == 20 ? run_rowsync<KK, 16, 1>(in, out, g, c, reps) : run_rowsync<KK, 16, 0>(in, out, g, c, reps); }
+        RC(1) RC(2) RC(3) RC(4) RC(6) RC(8)
+#undef RC
+        return -1.f;
+    }
     // vec 10 / 11: the burst form (pf = burst size), stores each step / stores in bursts too
     if (c.vec >= 10 && c.mrg == 2) {
 #define BC(KK) if (c.pf == KK) return c.vec == 11 ? run_burst<KK, 2, 1>(in, out, g, c, reps) : run_burst<KK, 2, 0>(in, out, g, c, reps);

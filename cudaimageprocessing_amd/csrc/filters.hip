@@ -1823,10 +1823,11 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     g.in_origin = 0; g.in_lo = 0; g.in_hi = g.N; g.out_origin = 0;
     g.in_frame_stride = g.N; g.out_frame_stride = g.N;
     // margin lanes per side: one is enough for the chain's 4-pixel reach; two make the strips 240
-    // pixels wide, whose rows start on 64-byte boundaries (+3 % measured), and are taken when that
-    // costs no extra strip (3840 = 16 x 240, 1920 = 8 x 240)
+    // pixels wide, whose rows start on 64-byte boundaries (+3..6 % measured), and are taken when that
+    // costs at most one strip in 31 (3840 = 16 x 240, 1920 = 8 x 240; 7680 = 32 x 240 against 31 strips
+    // of 248: 0.213 ms against 0.2275 for 4 frames)
     int mrg = tuning().chain_margin;
-    if (mrg != 1 && mrg != 2) mrg = (W + 239) / 240 <= (W + 247) / 248 ? 2 : 1;
+    if (mrg != 1 && mrg != 2) mrg = (i64)((W + 239) / 240) * 31 <= (i64)((W + 247) / 248) * 32 ? 2 : 1;
     const int outw = 4 * (64 - 2 * mrg);
     g.strips = (W + outw - 1) / outw;
     // tall bands amortise the 8 extra rows a band runs through the early stages, short ones keep the
@@ -1834,7 +1835,7 @@ int launch_chain(const void* d_in, void* d_out, int W, int H, int batch, float s
     // 30 and 36, 4 % at 42); shrink them only to fill the machine
     int rpb = tuning().chain_rows_per_band;
     if (rpb <= 0) {
-        rpb = 34;
+        rpb = W > 5760 ? 32 : 34;          // 7680-wide rows: 0.206 ms at 32 (and 30), 0.215 at 34, for 4 frames
         // (small batches: measured on 1, 2 and 4 4K frames and on single 1080p and 675x900 frames)
         while (rpb > 8 && (i64)batch * g.strips * ((H + rpb - 1) / rpb) < 4096) rpb >>= 1;
     }

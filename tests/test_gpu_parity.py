@@ -244,6 +244,34 @@ def test_chain_4k_frame_against_oracle(dev, golden):
     assert np.array_equal(d, golden.sobel(c, threads=8))
 
 
+def test_8k_frame_every_filter_against_oracle(dev, golden):
+    """north_star's target workload, "8K RGB batches": one 7680 x 4320 frame through every filter of the path
+    against the oracle (bit-exact; +-1 for the separable Gaussians), the fused chain against the four kernels,
+    and a batch of four such frames against the single-frame launches."""
+    w, h = 7680, 4320
+    img_d = ops.synth(8, w, h)
+    img = host(img_d)
+    a, b, c, d = [host(t) for t in ops.filter_chain(img_d)]
+    assert np.array_equal(a, golden.grayscale(img, threads=8))
+    assert np.abs(b.astype(np.int16) - golden.gaussian(a, 5, 1.0, threads=8).astype(np.int16)).max() <= GAUSS_TOL
+    assert np.array_equal(c, golden.medianblur(b, 3, threads=8))
+    assert np.array_equal(d, golden.sobel(c, threads=8))
+    assert torch.equal(ops.fused_chain(img_d), ops.filter_chain(img_d)[3])
+    assert np.array_equal(host(ops.mean_blur(img_d, 3)), golden.meanblur(img, 3, threads=8))
+    # the expensive oracle filters on the top 520 rows only: output rows 0..499 of the full frame depend on
+    # nothing below row 508 (radius 7 + 1 for the flat-index wrap), and the crop's bottom border lies below them
+    top = img[:520]
+    assert np.array_equal(host(ops.median_blur(img_d, 5))[:500], golden.medianblur(top, 5, threads=8)[:500])
+    assert np.array_equal(host(ops.gaussian_blur(img_d, 5, 1.0, direct=True))[:500], golden.gaussian(top, 5, 1.0, threads=8)[:500])
+    g15 = host(ops.gaussian_blur(img_d, 15, 2.5))[:500]
+    assert np.abs(g15.astype(np.int16) - golden.gaussian(top, 15, 2.5, threads=8)[:500].astype(np.int16)).max() <= GAUSS_TOL
+    batch = torch.stack([img_d, img_d.flip(0), img_d.flip(1), img_d]).contiguous()
+    for fn in (ops.sobel, lambda t: ops.median_blur(t, 3), lambda t: ops.gaussian_blur(t, 5, 1.0), lambda t: ops.fused_chain(t)):
+        out = fn(batch)
+        for i in range(4):
+            assert torch.equal(out[i], fn(batch[i].contiguous())), i
+
+
 @pytest.mark.parametrize("w,h", SIZES + [(3840, 270), (1920, 1080), (249, 64), (247, 9), (496, 12)])
 def test_fused_chain_equals_four_kernels(dev, golden, w, h):
     """mi_chain_gray_gauss5_median3_sobel_u8x4_dev is bit-identical to the four separate kernels,

@@ -80,6 +80,23 @@ report(f"the same chain as four kernels ({C})", "C2 chain", px, 32, lambda: ops.
 report(f"image load/write repack ({C})", ":107-132", px, 8, lambda: ops.image_load(fr.view(-1), out.view(-1)))
 del bufs
 
+# ---- north_star's "8K RGB batches": 4 frames of 7680 x 4320 (the same 531 MB per buffer as 16 4K frames)
+del fr, out
+torch.cuda.empty_cache()
+W8, H8, B8 = 7680, 4320, 4
+fr = ops.synth(8, W8, H8, batch=B8)
+out = torch.empty_like(fr)
+px8 = B8 * W8 * H8
+C8 = "4 x 7680x4320"
+report(f"grayscale ({C8})", "imageTools.cu:217-231", px8, 8, lambda: ops.grayscale(fr, out))
+report(f"Sobel ({C8})", ":255-285", px8, 8, lambda: ops.sobel(fr, out))
+report(f"mean 3x3 ({C8})", ":313-340", px8, 8, lambda: ops.mean_blur(fr, 3, out))
+report(f"median 3x3 ({C8})", "README.md:3", px8, 8, lambda: ops.median_blur(fr, 3, out))
+report(f"median 5x5 ({C8})", "README.md:3", px8, 8, lambda: ops.median_blur(fr, 5, out), 20, "VALU-bound")
+report(f"Gaussian 5x5 sigma 1, separable ({C8})", ":287-311", px8, 8, lambda: ops.gaussian_blur(fr, 5, 1.0, out), 20)
+report(f"Gaussian 15x15 sigma 2.5, separable ({C8})", ":287-311", px8, 8, lambda: ops.gaussian_blur(fr, 15, 2.5, out), 20)
+report(f"fused chain gray>gauss5>median3>Sobel ({C8})", "C2 chain", px8, 8, lambda: ops.fused_chain(fr, 1.0, out))
+
 # ---- C4 shape: one 32768 x 32768 image (4 GiB in, 4 GiB out)
 del fr, out
 torch.cuda.empty_cache()

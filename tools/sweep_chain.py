@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Sweep of the fused chain kernel's tuning knobs (mi_debug_set_tuning; "-" = 0, the default) on the
-bench workload: 16 x 3840x2160.  Prints ms per launch, two passes per setting."""
+bench workload: 16 x 3840x2160 (SWEEP_GEOMETRY=W,H,B for another).  Prints ms per launch, two passes per setting."""
 import os, sys, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from cudaimageprocessing_amd import ops
 
-W, H, B = 3840, 2160, 16
+W, H, B = (int(v) for v in os.environ.get("SWEEP_GEOMETRY", "3840,2160,16").split(","))
 frames = ops.synth(2, W, H, batch=B)
 out = torch.empty_like(frames)
 

@@ -132,13 +132,13 @@ static int check_filter(int filter, int w, int h, int ksize, float sigma)
     case MI_FILTER_SOBEL: return MI_OK;
     case MI_FILTER_GAUSSIAN:
     case MI_FILTER_GAUSSIAN_DIRECT:
-        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE)
-            return fail(MI_ERR_BAD_KERNEL_SIZE, "Gaussian kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, ksize);
+        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE_ANY)
+            return fail(MI_ERR_BAD_KERNEL_SIZE, "Gaussian kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE_ANY, ksize);
         if (!(sigma > 0.0f) || !isfinite(sigma)) return fail(MI_ERR_INVALID_ARG, "sigma must be positive and finite");
         return MI_OK;
     case MI_FILTER_MEAN:
-        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE)
-            return fail(MI_ERR_BAD_KERNEL_SIZE, "mean kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, ksize);
+        if (ksize < 1 || ksize % 2 == 0 || ksize > MI_MAX_KERNEL_SIZE_ANY)
+            return fail(MI_ERR_BAD_KERNEL_SIZE, "mean kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE_ANY, ksize);
         return MI_OK;
     case MI_FILTER_MEDIAN:
         if (ksize != 3 && ksize != 5) return fail(MI_ERR_BAD_KERNEL_SIZE, "median kernel size must be 3 or 5 (got %d)", ksize);
@@ -470,20 +470,9 @@ int mi_image_load(const uint8_t* bytes, uint8_t* pixels, size_t n_pixels)
 {
     if (!bytes || !pixels) return fail(MI_ERR_INVALID_ARG, "null pointer");
     if (n_pixels == 0) return MI_OK;
-    const size_t n = n_pixels * 4;
-    void *d_a = nullptr, *d_b = nullptr;
-    int rc = MI_OK;
-    hipError_t e = hipMalloc(&d_a, n);
-    if (e == hipSuccess) e = hipMalloc(&d_b, n);
-    if (e == hipSuccess) {
-        rc = host_upload(d_a, bytes, n);
-        if (rc == MI_OK) rc = launch_copy(d_a, d_b, n, nullptr);
-        if (rc == MI_OK) rc = hip_status(hipStreamSynchronize(nullptr), "mi_image_load");
-        if (rc == MI_OK) rc = host_download(pixels, d_b, n);
-    }
-    if (d_a) (void)hipFree(d_a);
-    if (d_b) (void)hipFree(d_b);
-    return rc ? rc : hip_status(e, "mi_image_load");
+    if (bytes != pixels && overlap(bytes, n_pixels * 4, pixels, n_pixels * 4)) return fail(MI_ERR_OVERLAP, "partially overlapping host buffers");
+    // (the same buffer twice is fine: a chunk is read before it is written)
+    return host_repack(bytes, pixels, n_pixels * 4);
 }
 
 int mi_image_write(const char* filename, const uint8_t* pixels, int w, int h)
@@ -732,8 +721,8 @@ int mi_spectrum_keep_top_dev(void* d_data, size_t n, size_t keep, void* stream)
 int mi_gaussian_kernel(int kernel_size, float sigma, float* out)
 {
     if (!out) return fail(MI_ERR_INVALID_ARG, "null pointer");
-    if (kernel_size < 1 || kernel_size % 2 == 0 || kernel_size > MI_MAX_KERNEL_SIZE)
-        return fail(MI_ERR_BAD_KERNEL_SIZE, "kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE, kernel_size);
+    if (kernel_size < 1 || kernel_size % 2 == 0 || kernel_size > MI_MAX_KERNEL_SIZE_ANY)
+        return fail(MI_ERR_BAD_KERNEL_SIZE, "kernel size must be odd, in [1,%d] (got %d)", MI_MAX_KERNEL_SIZE_ANY, kernel_size);
     if (!(sigma > 0.0f) || !isfinite(sigma)) return fail(MI_ERR_INVALID_ARG, "sigma must be positive and finite");
     gaussian_kernel_2d(kernel_size, sigma, out);
     return MI_OK;

@@ -5,6 +5,8 @@
 // execution scheme ("wave march", see common.h) is this library's own.
 // Build with -ffp-contract=off: every fused multiply-add is spelled out.
 #include <array>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 
 #include "common.h"
@@ -1255,6 +1257,33 @@ __global__ __launch_bounds__(256) void gauss_direct_kernel(const u32* __restrict
     out[(i64)y * g.W + x - g.out_origin] = o;
 }
 
+// The same for kernel sizes above 31, whose k*k weights no longer fit the kernel arguments: weights in device memory.
+__global__ __launch_bounds__(256) void gauss_direct_ptr_kernel(const u32* __restrict__ in, u32* __restrict__ out, const Geo g,
+                                                               int k, const float* __restrict__ wt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = g.y_begin + blockIdx.y;
+    const int frame = blockIdx.z;
+    if (x >= g.W) return;
+    in += (i64)frame * g.in_frame_stride;
+    out += (i64)frame * g.out_frame_stride;
+    u32 o = 0;
+    if (x >= 1 && x <= g.W - 2 && y >= 1 && y <= g.H - 2) {
+        const int r = k / 2;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int ky = -r; ky <= r; ky++)
+            for (int kx = -r; kx <= r; kx++) {
+                const u32 p = tap_px(in, g, (i64)(y + ky) * g.W + (x + kx));
+                const float kv = wt[(ky + r) * k + (kx + r)];
+                sx = __builtin_fmaf((float)(p & 0xffu), kv, sx);
+                sy = __builtin_fmaf((float)((p >> 8) & 0xffu), kv, sy);
+                sz = __builtin_fmaf((float)((p >> 16) & 0xffu), kv, sz);
+            }
+        o = (u32)sx | ((u32)sy << 8) | ((u32)sz << 16) | 0xFF000000u;
+    }
+    out[(i64)y * g.W + x - g.out_origin] = o;
+}
+
 // imageMeanBlur, imageTools.cu:313-340, for any odd k.
 __global__ __launch_bounds__(256) void mean_generic_kernel(const u32* __restrict__ in,
                                                            u32* __restrict__ out, const Geo g,
@@ -1773,17 +1802,26 @@ static u32 mean_magic(int k)
 // ceil(2^32 / k^2) for k = 17..31 when (s * m) >> 32 == s / k^2 for every s <= 255 k^2, else 0
 static u32 mean_magic32(int k)
 {
-    static const std::array<u32, 32> table = [] {
+    auto magic = [](int ks) {
+        const uint64_t d = (uint64_t)ks * ks, m = ((1ull << 32) + d - 1) / d;
+        bool ok = m < (1ull << 32);
+        for (uint64_t sum = 0; sum <= 255u * d && ok; sum++) ok = ((sum * m) >> 32) == sum / d;
+        return ok ? (u32)m : 0u;
+    };
+    static const std::array<u32, 32> table = [&] {
         std::array<u32, 32> t{};
-        for (int ks = 17; ks <= 31; ks += 2) {
-            const uint64_t d = (uint64_t)ks * ks, m = ((1ull << 32) + d - 1) / d;
-            bool ok = m < (1ull << 32);
-            for (uint64_t sum = 0; sum <= 255u * d && ok; sum++) ok = ((sum * m) >> 32) == sum / d;
-            t[ks] = ok ? (u32)m : 0u;
-        }
+        for (int ks = 17; ks <= 31; ks += 2) t[ks] = magic(ks);
         return t;
     }();
-    return (k >= 0 && k < 32) ? table[k] : 0u;
+    if (k >= 0 && k < 32) return table[k];
+    // larger sizes (the LDS-tile kernel): verified on first use, then remembered
+    static std::mutex mu;
+    static std::array<u32, MI_MAX_KERNEL_SIZE_ANY + 1> big{};
+    static std::array<bool, MI_MAX_KERNEL_SIZE_ANY + 1> known{};
+    if (k > MI_MAX_KERNEL_SIZE_ANY) return 0u;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[k]) { big[k] = magic(k); known[k] = true; }
+    return big[k];
 }
 
 template <int R>
@@ -1903,10 +1941,13 @@ int launch_filter(const FilterArgs& a)
     const bool mean_prefix = a.filter == MI_FILTER_MEAN && a.ksize >= 17 && a.ksize <= 31 && mean_magic32(a.ksize) &&
                              tuning().mean_prefix;
     const bool mean_generic = a.filter == MI_FILTER_MEAN && (a.ksize < 3 || a.ksize > 15) && !mean_prefix;
-    if (mean_generic && a.ksize >= 17 && a.ksize <= 31 && mean_magic32(a.ksize)) {
+    // sizes above 31 (the reference takes any odd size, imageTools.cu:313-340): the LDS-tile kernel while its tile and
+    // border fit 64 KiB (k <= 49), one lane per pixel beyond
+    const size_t mean_tile_lds = ((size_t)(MT_H + 2 * (a.ksize / 2)) * (MT_W + 2 * (a.ksize / 2)) +
+                                  2 * (size_t)(MT_H + 2 * (a.ksize / 2)) * MT_W) * sizeof(u32);
+    if (mean_generic && a.ksize >= 17 && mean_tile_lds <= 64 * 1024 && mean_magic32(a.ksize)) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
-        const int r = a.ksize / 2;
-        const size_t lds = ((size_t)(MT_H + 2 * r) * (MT_W + 2 * r) + 2 * (size_t)(MT_H + 2 * r) * MT_W) * sizeof(u32);
+        const size_t lds = mean_tile_lds;
         const int tiles_y = (rows + MT_H - 1) / MT_H;
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {
             const int nb = std::min(65535, a.batch - f0);
@@ -1946,6 +1987,21 @@ int launch_filter(const FilterArgs& a)
     }
     if (direct || mean_generic) {
         g.rows_per_band = 1; g.bands = rows; g.strips = 1; g.total_waves = 0; g.xcd_remap = 0;
+        // Gaussian sizes above 31: the k*k weights (host-generated, like generateGaussianKernal's) exceed the
+        // kernel arguments and go through a device buffer made for this call -- such a call allocates,
+        // copies synchronously and waits for its stream before it frees the buffer (not capturable)
+        float* big_weights = nullptr;
+        if (direct && a.ksize > MI_MAX_KERNEL_SIZE) {
+            std::vector<float> w((size_t)a.ksize * a.ksize);
+            gaussian_kernel_2d(a.ksize, a.sigma, w.data());
+            hipError_t e = hipMalloc((void**)&big_weights, w.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(big_weights, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { if (big_weights) (void)hipFree(big_weights); return hip_status(e, "Gaussian weight table"); }
+        }
+        struct FreeWeights {
+            float* p; hipStream_t s;
+            ~FreeWeights() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } }
+        } free_weights{big_weights, a.stream};
         for (int f0 = 0; f0 < a.batch; f0 += 65535) {
             const int nb = std::min(65535, a.batch - f0);
             for (int r0 = 0; r0 < rows; r0 += 65535) {
@@ -1955,7 +2011,9 @@ int launch_filter(const FilterArgs& a)
                 const dim3 grid((W + 255) / 256, nr, nb);
                 const u32* pin = in + (i64)f0 * in_frame;
                 u32* pout = out + (i64)f0 * out_frame;
-                if (direct) {
+                if (direct && a.ksize > MI_MAX_KERNEL_SIZE) {
+                    gauss_direct_ptr_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize, big_weights);
+                } else if (direct) {
                     Weights2D wt;
                     gaussian_kernel_2d(a.ksize, a.sigma, wt.w);
                     gauss_direct_kernel<<<grid, 256, 0, a.stream>>>(pin, pout, gg, a.ksize, wt);

@@ -329,6 +329,51 @@ int host_download(void* host, const void* dev, size_t bytes)
     return hip_status(e, "staged device-to-host copy");
 }
 
+// imageLoadWrapper's shape (imageTools.cu:158-183: H2D, the repack kernel -- a copy --, D2H) through the
+// pipe's cached buffers, a chunk at a time: chunk c is staged, copied up, repacked on the device and copied
+// down on slot c % 3's stream while the host stages the next one; its pinned output is unloaded when the slot
+// comes round again.  Nothing is allocated per call (the reference allocates two managed buffers per call).
+int host_repack(const void* src, void* dst, size_t bytes)
+{
+    int device = 0;
+    int rc = current_device(&device);
+    if (rc) return rc;
+    HostPipe& pipe = g_pipes[device];
+    std::lock_guard<std::mutex> lock(pipe.mu);
+    const size_t chunk = std::min(bytes, STAGE_CHUNK);
+    hipError_t e = pipe.reserve(chunk, chunk, chunk);
+    if (e != hipSuccess) return hip_status(e, "host-tier staging buffers");
+    pipe.crews(crew_helpers());
+    constexpr int NSLOT = HostPipe::NSLOT;
+    const int n_chunks = (int)((bytes + STAGE_CHUNK - 1) / STAGE_CHUNK);
+    auto span = [&](int c, size_t* off, size_t* n) { *off = (size_t)c * STAGE_CHUNK; *n = std::min(STAGE_CHUNK, bytes - *off); };
+    auto unload = [&](int c) {
+        Slot& s = pipe.slot[c % NSLOT];
+        size_t off, n;
+        span(c, &off, &n);
+        const hipError_t err = hipEventSynchronize(s.done);
+        if (err == hipSuccess) pipe.crew_out->copy((char*)dst + off, s.pin_out, n);
+        return err;
+    };
+    for (int c = 0; c < n_chunks && e == hipSuccess && rc == MI_OK; c++) {
+        Slot& s = pipe.slot[c % NSLOT];
+        if (c >= NSLOT) e = unload(c - NSLOT);
+        if (e != hipSuccess) break;
+        size_t off, n;
+        span(c, &off, &n);
+        pipe.crew_in->copy(s.pin_in, (const char*)src + off, n);
+        e = hipMemcpyAsync(s.dev[0], s.pin_in, n, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) rc = launch_copy(s.dev[0], s.dev[1], n, s.stream);
+        if (e == hipSuccess && rc == MI_OK) e = hipMemcpyAsync(s.pin_out, s.dev[1], n, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess && rc == MI_OK) e = hipEventRecord(s.done, s.stream);
+    }
+    for (int c = std::max(0, n_chunks - NSLOT); c < n_chunks && e == hipSuccess && rc == MI_OK; c++) e = unload(c);
+    if (rc != MI_OK || e != hipSuccess)
+        for (Slot& s : pipe.slot) if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (rc) return rc;
+    return hip_status(e, "host-tier repack pipeline");
+}
+
 // ops are validated by the caller (api.hip).
 int host_run_ops(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* ops, int n_ops, int chunk_rows_hint)
 {

@@ -86,6 +86,7 @@ int host_strip_run(const uint8_t* in, uint8_t* out, int w, int h, const mi_op* o
                    int n_devices);
 int host_release();
 // Blocking whole-buffer copies between pageable host memory and the device, staged through pinned chunks.
+int host_repack(const void* src, void* dst, size_t bytes);      // host -> device -> repack kernel -> host, chunked
 int host_upload(void* dev, const void* host, size_t bytes);
 int host_download(void* host, const void* dev, size_t bytes);
 // Device scratch of at least `bytes` for a blocking host-tier call, kept between calls (freed by

@@ -46,7 +46,12 @@ extern "C" {
 #define MI_ERR_IO (-5)            /* file could not be written */
 #define MI_ERR_SELFTEST (-6)      /* mi_selftest found a wrong result */
 
-#define MI_MAX_KERNEL_SIZE 31
+#define MI_MAX_KERNEL_SIZE 31      /* the sizes with specialised kernels */
+/* The reference takes any odd kernalSize (imageTools.cu:313-340, :478-502); so do the Gaussian and the mean
+ * here, up to this bound.  Above MI_MAX_KERNEL_SIZE they run on generic kernels (mean: LDS tiles up to 49,
+ * then one lane per pixel; Gaussian: one lane per pixel, and the call allocates a k*k weight table,
+ * synchronises its stream and cannot be captured in a graph): correct, bit-exact, slow. */
+#define MI_MAX_KERNEL_SIZE_ANY 255
 /* 2-D transforms: each of rows, cols is in [2, MI_FFT_MAX_ANY], or a power of two up to
  * MI_FFT_MAX_POW2; a plane holds fewer than 2^28 points (2 GiB of interleaved fp32). */
 #define MI_FFT_MAX_ANY 8192
@@ -85,7 +90,7 @@ int mi_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, vo
  * mode MI_GAUSS_SEPARABLE: row pass then column pass with 1-D weights (max |delta| <= 1 LSB
  *   against the reference's direct 2-D sum, which truncates float->u8, imageTools.cu:306-308);
  * mode MI_GAUSS_DIRECT: the reference's k x k sum in its own order, bit-exact, slower.
- * kernel_size: odd, 1..MI_MAX_KERNEL_SIZE; sizes above 15 always take the direct form. */
+ * kernel_size: odd, 1..MI_MAX_KERNEL_SIZE_ANY; sizes above 15 always take the direct form. */
 #define MI_GAUSS_SEPARABLE 0
 #define MI_GAUSS_DIRECT 1
 int mi_gaussian_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,

@@ -67,7 +67,7 @@ def test_argument_errors_need_no_gpu(mi):
     assert lib.mi_sobel_u8x4_dev(p, p + 1024, 2, 8, 1, None) == -1            # W < 3
     assert lib.mi_sobel_u8x4_dev(p, p, 4, 4, 1, None) == -4                   # in/out overlap
     assert lib.mi_gaussian_u8x4_dev(p, p + 1024, 4, 4, 1, 4, 1.0, 0, None) == -2   # even size
-    assert lib.mi_gaussian_u8x4_dev(p, p + 1024, 4, 4, 1, 33, 1.0, 0, None) == -2  # too large (31 is the limit)
+    assert lib.mi_gaussian_u8x4_dev(p, p + 1024, 4, 4, 1, 257, 1.0, 0, None) == -2  # too large (255 is the limit)
     assert lib.mi_gaussian_u8x4_dev(p, p + 1024, 4, 4, 1, 5, 0.0, 0, None) == -1   # sigma
     assert lib.mi_gaussian_u8x4_dev(p, p + 1024, 4, 4, 1, 5, 1.0, 7, None) == -1   # mode
     assert lib.mi_meanblur_u8x4_dev(p, p + 1024, 4, 4, 1, 0, None) == -2

@@ -244,6 +244,36 @@ def test_chain_4k_frame_against_oracle(dev, golden):
     assert np.array_equal(d, golden.sobel(c, threads=8))
 
 
+@pytest.mark.parametrize("k", [33, 41, 49, 51, 63, 101])
+def test_kernel_sizes_above_31_against_oracle(dev, golden, k):
+    """The reference takes any odd kernalSize (imageTools.cu:313-340, :478-502; its 1-pixel guard and flat-index
+    taps whatever the size).  Above 31 the mean runs on the LDS-tile kernel (to 49) and then one lane per pixel,
+    the Gaussian one lane per pixel with its weights in device memory: bit-exact against the oracle, whole frames,
+    a batch, and row strips; also through the host tier."""
+    for (w, h) in ((150, 97), (64, 40)):
+        img = make("random", w, h, k)
+        d = to_dev(img, dev)
+        assert np.array_equal(host(ops.mean_blur(d, k)), golden.meanblur(img, k)), (w, h)
+        if k <= 41:
+            assert np.array_equal(host(ops.gaussian_blur(d, k, 0.3 * k)), golden.gaussian(img, k, 0.3 * k)), (w, h)
+    w, h = 150, 97
+    img = make("natural", w, h, 3)
+    d = to_dev(img, dev)
+    batch = torch.stack([d, d.flip(0)]).contiguous()
+    mb = ops.mean_blur(batch, k)
+    assert torch.equal(mb[0], ops.mean_blur(d, k)) and torch.equal(mb[1], ops.mean_blur(batch[1].contiguous(), k))
+    # rows [30, 60) as a strip with its halo
+    halo = k // 2 + 1
+    r0, r1 = max(0, 30 - halo), min(h, 60 + halo)
+    out = torch.empty((30, w, 4), dtype=torch.uint8, device=dev)
+    ops.filter_strip(_lib.FILTER_MEAN, d[r0:r1].contiguous(), out, w, h, r0, 30, 60, k, 0.0)
+    assert torch.equal(out, ops.mean_blur(d, k)[30:60])
+    if k == 33:
+        got = np.empty_like(img)
+        ops.run_ops(got, img, w, h, ops.parse_ops(f"mean:{k},gauss:{k}:9.5"))
+        assert np.array_equal(got, golden.gaussian(golden.meanblur(img, k), k, 9.5))
+
+
 def test_8k_frame_every_filter_against_oracle(dev, golden):
     """north_star's target workload, "8K RGB batches": one 7680 x 4320 frame through every filter of the path
     against the oracle (bit-exact; +-1 for the separable Gaussians), the fused chain against the four kernels,

@@ -42,7 +42,7 @@ const Knob KNOBS[] = {
     {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_TWOPASS_NT", &Tuning::fft_twopass_nt},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
-    {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
+    {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
 };
 Tuning& tuning_rw()
 {
@@ -479,8 +479,12 @@ int mi_image_write(const char* filename, const uint8_t* pixels, int w, int h)
 {
     if (!filename || !pixels || w <= 0 || h <= 0) return fail(MI_ERR_INVALID_ARG, "bad argument");
     // The reference round-trips the pixels through the device (imageWrite kernel, a copy) before
-    // encoding; the bytes are identical, so the encoder reads the caller's buffer directly.
-    return write_png_rgba(filename, pixels, w, h);
+    // encoding; the bytes are identical, so the encoder reads the caller's buffer directly.  The encoder is
+    // the reference's own, stb_image_write v1.16 (imageTools.cu:152): the same file, byte for byte.
+    // MI_PNG_ZLIB=1 selects the zlib encoder instead (smaller files, 3x faster on large images).
+    if (tuning().png_zlib) return write_png_rgba(filename, pixels, w, h);
+    if ((int64_t)w * 4 > 0x7fffffff) return fail(MI_ERR_INVALID_ARG, "image too wide for the PNG encoder");
+    return png_write_rgba_stb(filename, pixels, w, h) ? MI_OK : fail(MI_ERR_IO, "cannot write %s", filename);
 }
 
 int mi_grayscale_u8x4(const uint8_t* in, uint8_t* out, int w, int h)

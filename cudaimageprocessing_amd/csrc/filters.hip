@@ -540,7 +540,7 @@ template <int R, int POL>
 __global__ __launch_bounds__(256, MI_GW_WAVES) void gauss_wide_kernel(const u32* __restrict__ in, u32* __restrict__ out,
                                                             const Geo g, const GaussWide gw)
 {
-    constexpr int K = 2 * R + 1, NP = R + 1;
+    constexpr int NP = R + 1;
     constexpr int HOPS = (R + 3) / 4;
     constexpr int N1 = R < 4 ? R : 4, N2 = R > 4 ? R - 4 : 1;
     MI_MARCH_PROLOGUE();

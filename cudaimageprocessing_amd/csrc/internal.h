@@ -32,6 +32,7 @@ struct Tuning {
     int fft_twopass_nt = 0;       // MI_FFT_TWOPASS_NT: non-temporal stores
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
+    int png_zlib = 0;             // MI_PNG_ZLIB: mi_image_write encodes with zlib instead of the reference's stb_image_write
     int mean_prefix = 1;          // MI_MEAN_PREFIX: mean 17x17..31x31 as a wave march on prefix sums (0: LDS tiles)
     int host_copy_threads = 4;    // MI_HOST_COPY_THREADS: host threads per direction that stage a chunk between pageable and pinned memory
     int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
@@ -68,6 +69,7 @@ void gaussian_kernel_2d(int k, float sigma, float* out);
 // Normalised 1-D weights whose outer product is the 2-D kernel (up to rounding).
 void gaussian_kernel_1d(int k, float sigma, float* out);
 
+int png_write_rgba_stb(const char* filename, const unsigned char* px, int w, int h);     // stb_write.cpp; 0 on failure
 int launch_copy(const void* src, void* dst, size_t bytes, hipStream_t s);
 int launch_synth(void* out, uint64_t seed, uint64_t first, uint64_t count, hipStream_t s);
 int launch_sobel_table(void* out, uint32_t count, hipStream_t s);

@@ -130,3 +130,24 @@ def test_imgtool_decodes_jpeg_like_the_committed_stb_fixture(tmp_path):
     want = np.asarray(Image.open(os.path.join(root, "tests", "golden", "lord_decoded_by_stb.png")).convert("RGB"))
     assert np.array_equal(got, want)
 
+
+
+def test_image_write_reproduces_the_reference_file_byte_for_byte(tmp_path):
+    """imageWriteWrapper ends in stbi_write_png (imageTools.cu:152, stb_image_write v1.16); mi_image_write calls
+    the same encoder.  The reference ships one file its wrapper wrote: image/output.jpg (a PNG), committed as
+    tests/golden/upstream_output_of_lord.png.  Decoded and written again through the C ABI, it comes out as
+    the same 829 886 bytes -- the write path pinned by a reference-held artefact, no GPU involved.
+    The zlib encoder (MI_PNG_ZLIB=1) writes another file with the same pixels."""
+    import numpy as np
+    from PIL import Image
+    from cudaimageprocessing_amd import ops
+    up = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "upstream_output_of_lord.png")
+    px = np.ascontiguousarray(np.asarray(Image.open(up).convert("RGBA")))
+    h, w = px.shape[:2]
+    out = str(tmp_path / "again.png")
+    ops.imageWriteWrapper(out, px, w, h)
+    assert open(out, "rb").read() == open(up, "rb").read()
+    with ops.tuning(MI_PNG_ZLIB=1):
+        ops.imageWriteWrapper(out, px, w, h)
+    assert open(out, "rb").read() != open(up, "rb").read()
+    assert np.array_equal(np.asarray(Image.open(out).convert("RGBA")), px)

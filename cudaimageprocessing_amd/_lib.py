@@ -64,6 +64,8 @@ SIGNATURES = {
     "mi_spectrum_keep_top_dev": [_vp, _sz, _sz, _vp],
     "mi_selftest": [],
     "mi_gaussian_kernel": [_i, _f, _vp],
+    "mi_strip_rows": [_i, _i, _i, _vp, _vp],
+    "mi_strip_stage_u8x4_dev": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _f],
     "mi_debug_set_tuning": [C.c_char_p, _i],
     "mi_debug_get_tuning": [C.c_char_p, _vp],
     "mi_version": [],

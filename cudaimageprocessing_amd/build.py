@@ -7,7 +7,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libmi_imagetools.so")
 
-SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "noalloc.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
+SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "noalloc.hip", "strips.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
 HEADERS = ["common.h", "internal.h", "median5_network.h", "fft_twopass.h",
            os.path.join("..", "..", "include", "mi_imagetools.h"),
            os.path.join("..", "..", "include", "imageTools.h")]

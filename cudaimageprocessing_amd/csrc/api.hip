@@ -124,7 +124,7 @@ static int check_image(const void* in, const void* out, int w, int h, int batch)
     return MI_OK;
 }
 
-static int check_filter(int filter, int w, int h, int ksize, float sigma)
+int check_filter(int filter, int w, int h, int ksize, float sigma)
 {
     if (filter == MI_FILTER_GRAYSCALE) return MI_OK;
     if (w < 3 || h < 3) return fail(MI_ERR_INVALID_ARG, "stencil filters need w>=3 and h>=3 (got %dx%d)", w, h);

@@ -413,6 +413,23 @@ def strip_run_ops(out, image, ops_list, devices=(0,)):
     check(lib().mi_strip_run_ops_u8x4(image.ctypes.data, out.ctypes.data, w, h, arr, n_ops, dev, len(devices)))
 
 
+def strip_rows(h, n, i):
+    """Row range [y0, y1) of strip i of n (mi_strip_rows)."""
+    y0, y1 = C.c_int(0), C.c_int(0)
+    check(lib().mi_strip_rows(int(h), int(n), int(i), C.byref(y0), C.byref(y1)))
+    return y0.value, y1.value
+
+
+def strip_stage(bufs_in, bufs_out, w, h, devices, pad_rows, filter_id, ksize=3, sigma=0.0):
+    """mi_strip_stage_u8x4_dev: one filter over device-resident row strips.  bufs_in[i] / bufs_out[i]: uint8
+    tensors of (pad_rows + rows_i + pad_rows, w, 4) on devices[i], the strip's rows starting at row pad_rows."""
+    n = len(devices)
+    pin = (C.c_void_p * n)(*[b.data_ptr() for b in bufs_in])
+    pout = (C.c_void_p * n)(*[b.data_ptr() for b in bufs_out])
+    dev = (C.c_int * n)(*devices)
+    check(lib().mi_strip_stage_u8x4_dev(pin, pout, int(w), int(h), dev, n, int(pad_rows), int(filter_id), int(ksize), float(sigma)))
+
+
 def fft_highpass_workspace_bytes(width, height, batch=1):
     n = C.c_size_t(0)
     check(lib().mi_fft_highpass_batch_workspace_bytes(int(width), int(height), int(batch), C.byref(n)))

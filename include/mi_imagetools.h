@@ -235,6 +235,20 @@ int mi_run_ops_chunked_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const
  *                          the accumulated halo of the list from `in`); out must not be in when G > 1.
  * The calling thread's current device is unchanged on return.  (Device-resident strips with an RCCL
  * halo exchange are cudaimageprocessing_amd/shard.py over mi_filter_strip_u8x4_dev.) */
+/* Device-RESIDENT row strips, one process (no counterpart upstream; BASELINE.json config 4 for a C++ caller):
+ * strip i of a w x h image -- rows [y0, y1) = mi_strip_rows(h, G, i) -- lives on devices[i] in the middle of a
+ * device buffer of (pad_rows + rows + pad_rows) image rows, its first row at row pad_rows.  One call = one filter
+ * over every strip: each device's copy stream brings the neighbours' edge rows straight into the pad rows
+ * (hipMemcpyPeerAsync, point to point, no host copy), its main stream filters the interior rows meanwhile, then
+ * waits for the copies on an event and filters the two edge bands.  d_in[i] / d_out[i] are the strip buffers
+ * on devices[i] (they must differ; swap them between the stages of a chain); pad_rows >=
+ * mi_filter_halo_rows(filter, param_i).  Blocking: on return every device has finished and d_out[i] holds the
+ * filtered strip (its pad rows are undefined).  Output == the single-device call on the whole image, bit for
+ * bit.  An ordinal may repeat (its strips then take turns on that device).  The RCCL form of the same
+ * decomposition, one process per GPU, is cudaimageprocessing_amd/shard.py. */
+int mi_strip_rows(int h, int n_devices, int i, int *y0, int *y1);
+int mi_strip_stage_u8x4_dev(void *const *d_in, void *const *d_out, int w, int h, const int *devices,
+                            int n_devices, int pad_rows, int filter, int param_i, float param_f);
 int mi_batch_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, int n_frames, const mi_op *ops,
                           int n_ops, const int *devices, int n_devices);
 int mi_strip_run_ops_u8x4(const uint8_t *in, uint8_t *out, int w, int h, const mi_op *ops, int n_ops,

@@ -283,3 +283,55 @@ def test_host_release_concurrent_with_spectral_call(dev):
     r.join(timeout=30)
     assert not c.is_alive() and not r.is_alive(), "deadlock between mi_host_release and mi_fft_highpass_u8x4"
     assert not errors, errors
+
+
+@pytest.mark.parametrize("n_strips", [1, 2, 3, 5])
+def test_device_resident_strips_behind_the_c_abi(dev, golden, n_strips):
+    """mi_strip_stage_u8x4_dev: an image in row strips that stay on the devices, neighbour halos copied device
+    to device into poisoned pad rows, interior rows filtered meanwhile.  One GPU here, so ordinal 0 is listed
+    n times (as test_multi_device_entry_points_of_the_c_abi does): what is under test is the decomposition --
+    the stitched strips of a chain of stages equal the single launch on the whole image, bit for bit, and the
+    oracle."""
+    w, h = 264, 301
+    img = S.pattern_image("natural", w, h, 21)
+    whole = torch.from_numpy(img).to(dev)
+    stages = [(_lib.FILTER_SOBEL, 3, 0.0), (_lib.FILTER_MEDIAN, 5, 0.0), (_lib.FILTER_GAUSSIAN, 15, 2.5),
+              (_lib.FILTER_MEAN, 9, 0.0), (_lib.FILTER_GAUSSIAN_DIRECT, 5, 1.0)]
+    pad = max(_lib.lib().mi_filter_halo_rows(f, k) for f, k, _ in stages)
+    devices = (0,) * n_strips
+    rows = [ops.strip_rows(h, n_strips, i) for i in range(n_strips)]
+    assert rows[0][0] == 0 and rows[-1][1] == h and all(rows[i][1] == rows[i + 1][0] for i in range(n_strips - 1))
+    bufs = [[torch.full((pad + y1 - y0 + pad, w, 4), 0xA5, dtype=torch.uint8, device=dev) for (y0, y1) in rows] for _ in range(2)]
+    for i, (y0, y1) in enumerate(rows):
+        bufs[0][i][pad:pad + y1 - y0] = whole[y0:y1]
+    cur, want, ref = 0, whole, img
+    for f, k, s in stages:
+        for b in bufs[cur ^ 1]:
+            b.fill_(0x5A)                                   # the output buffers' pad rows and strips start poisoned
+        ops.strip_stage(bufs[cur], bufs[cur ^ 1], w, h, devices, pad, f, k, s)
+        cur ^= 1
+        want = {_lib.FILTER_SOBEL: lambda t: ops.sobel(t), _lib.FILTER_MEDIAN: lambda t: ops.median_blur(t, k),
+                _lib.FILTER_GAUSSIAN: lambda t: ops.gaussian_blur(t, k, s), _lib.FILTER_MEAN: lambda t: ops.mean_blur(t, k),
+                _lib.FILTER_GAUSSIAN_DIRECT: lambda t: ops.gaussian_blur(t, k, s, direct=True)}[f](want)
+        got = torch.cat([bufs[cur][i][pad:pad + y1 - y0] for i, (y0, y1) in enumerate(rows)])
+        assert torch.equal(got, want), (n_strips, f, k)
+    # the oracle on the first two (bit-exact) stages
+    two = golden.medianblur(golden.sobel(img), 5)
+    b2 = [[torch.full((pad + y1 - y0 + pad, w, 4), 0xA5, dtype=torch.uint8, device=dev) for (y0, y1) in rows] for _ in range(2)]
+    for i, (y0, y1) in enumerate(rows):
+        b2[0][i][pad:pad + y1 - y0] = whole[y0:y1]
+    ops.strip_stage(b2[0], b2[1], w, h, devices, pad, _lib.FILTER_SOBEL, 3, 0.0)
+    ops.strip_stage(b2[1], b2[0], w, h, devices, pad, _lib.FILTER_MEDIAN, 5, 0.0)
+    got = torch.cat([b2[0][i][pad:pad + y1 - y0] for i, (y0, y1) in enumerate(rows)]).cpu().numpy()
+    assert np.array_equal(got, two)
+    # argument errors: a strip thinner than the halo, too few pad rows, in == out
+    if n_strips == 5:                                        # 20 rows in 5 strips of 4: thinner than 8 halo rows
+        small = [[torch.zeros((pad + 4 + pad, 64, 4), dtype=torch.uint8, device=dev) for _ in range(5)] for _ in range(2)]
+        with pytest.raises(_lib.MiError):
+            ops.strip_stage(small[0], small[1], 64, 20, devices, pad, _lib.FILTER_GAUSSIAN, 15, 2.5)
+    if n_strips > 1:
+        with pytest.raises(_lib.MiError):
+            ops.strip_stage(bufs[0], bufs[1], w, h, devices, 1, _lib.FILTER_MEDIAN, 5, 0.0)
+    with pytest.raises(_lib.MiError) as e:
+        ops.strip_stage(bufs[0], bufs[0], w, h, devices, pad, _lib.FILTER_SOBEL, 3, 0.0)
+    assert e.value.code == -4

@@ -283,6 +283,58 @@ void run_cols2p_buf(const char* name, const float* in, float* out, int planes, i
            hipGetErrorString(hipGetLastError()));
 }
 
+// persistent form of cols2p_buf_k: a block owns `per` consecutive tiles (XCD-contiguous blocks), bulk loads, bulk stores
+template <int SB>
+__global__ __launch_bounds__(512, 4) void cols2p_persist_k(const float* __restrict__ in, float* __restrict__ out, int total_tiles)
+{
+    extern __shared__ float lds_pad_[];
+    constexpr int R2 = 1024, RX = 4, NCOL = 16, T = 32;
+    const int tid = threadIdx.x, c = tid % NCOL, t = tid / NCOL;
+    const unsigned nblk = gridDim.x, b = blockIdx.x;
+    const unsigned q = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int per = (total_tiles + nblk - 1) / nblk;
+    constexpr u32b plane_bytes = 4096u * 4096u * 8u, row_bytes = 4096 * 8;
+    constexpr u32b in_step = T * RX * row_bytes, out_step = T * row_bytes;
+    for (int it = 0; it < per; it++) {
+        const int tile = logical * per + it;
+        if (tile >= total_tiles) break;
+        const int cg = tile & 255, u = tile >> 8, n1 = u & 3, plane = u >> 2;
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (i64)plane * 4096 * 8192), 0, (int)plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (i64)plane * 4096 * 8192), 0, (int)plane_bytes, 0x00020000);
+        const u32b col_bytes = (u32b)(cg * NCOL + c) * 8u;
+        const u32b voff_in = ((u32b)n1 + (u32b)t * RX) * row_bytes + col_bytes;
+        const u32b voff_out = ((u32b)R2 * n1 + (u32b)t) * row_bytes + col_bytes;
+        u32x2bb v[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) v[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, voff_in, j * in_step, 0);
+        if (SB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 32; j++) __builtin_amdgcn_raw_buffer_store_b64(v[j], rout, voff_out, j * out_step, 0);
+        if (SB) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int SB>
+void run_cols2p_persist(const char* name, const float* in, float* out, int planes, int grid, int lds_bytes)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int tiles = planes * 1024;
+    hipFuncSetAttribute((const void*)cols2p_persist_k<SB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int i = 0; i < 3; i++) cols2p_persist_k<SB><<<grid, 512, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e0);
+    const int reps = 10;
+    for (int i = 0; i < reps; i++) cols2p_persist_k<SB><<<grid, 512, lds_bytes>>>(in, out, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-64s grid %5d lds %6d  %.3f ms  %.0f GB/s  (%s)\n", name, grid, lds_bytes, ms, (double)planes * 4096 * 65536.0 / ms / 1e6,
+           hipGetErrorString(hipGetLastError()));
+}
+
 template <int V, bool COL, bool PERSIST>
 void run(const char* name, const float* in, float* out, int total_lines, int grid)
 {
@@ -312,6 +364,10 @@ int main()
     if (getenv("COLS2P")) {
         const int L = 76 * 1024;
         const int P = getenv("PLANES") ? atoi(getenv("PLANES")) : planes;
+        run_cols2p_persist<1>("persistent, block-contiguous tiles, bulk loads then bulk stores", in, out, P, 512, L);
+        run_cols2p_persist<0>("persistent, block-contiguous tiles, compiler's order", in, out, P, 512, L);
+        run_cols2p_persist<1>("persistent bulk, 1024 blocks", in, out, P, 1024, L);
+        run_cols2p_persist<1>("persistent bulk, 2048 blocks", in, out, P, 2048, L);
         run_cols2p_buf<false, false>("buffer ops, b64 16 cols DIT, one block per tile, XCD-contiguous", in, out, P, L);
         run_cols2p_buf<false, true>("buffer ops + table prologue + barrier, same", in, out, P, L);
         run_cols2p_buf<false, true, 1>("global loads, buffer stores, same", in, out, P, L);

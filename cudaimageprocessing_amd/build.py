@@ -23,6 +23,12 @@ import shlex  # noqa: E402
 FLAGS += shlex.split(os.environ.get("MI_EXTRA_CXXFLAGS", ""))
 
 
+# Per-file flags.  fft.hip: the SLP vectoriser pairs the butterflies' scalar fp32 operations into v_pk_* ones --
+# which issue at the scalar rate on this part -- and pays for it in register shuffles (198 v_mov in the cols
+# kernel of the two-pass plan, 128 registers with spills to scratch; without it 85 registers, no spills).
+FILE_FLAGS = {"fft.hip": ["-fno-slp-vectorize"]}
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -43,7 +49,7 @@ def build(force=False, verbose=False):
         if not os.path.exists(src):
             continue
         obj = os.path.join(_CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -24,3 +24,13 @@ python3 $root/tools/pmc_summary.py $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WR
 cat $out/${tag}_traffic.txt
 f=$(find $out/${tag}_stats -name '*kernel_stats.csv' | head -1)
 cp "$f" $out/${tag}_kernel_stats.csv && cat $out/${tag}_kernel_stats.csv
+
+# 4. the FFT round trip (C5): kernel times and HBM traffic of the two-pass kernels (tools/bench_fft.py: 16 planes of 4096x4096)
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_fft_stats -- python3 $root/tools/bench_fft.py > $out/${tag}_fft_stats.log 2>&1 || { echo "fft stats pass failed"; tail -5 $out/${tag}_fft_stats.log; exit 1; }
+f=$(find $out/${tag}_fft_stats -name '*kernel_stats.csv' | head -1)
+cp "$f" $out/${tag}_fft_kernel_stats.csv && grep -E "Name|fft" $out/${tag}_fft_kernel_stats.csv | cut -c1-200
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_fft_pmc_$c -- python3 $root/tools/bench_fft.py > $out/${tag}_fft_pmc_$c.log 2>&1 || { echo "fft pass $c failed"; tail -5 $out/${tag}_fft_pmc_$c.log; exit 1; }
+done
+python3 $root/tools/pmc_summary.py $out/${tag}_fft_pmc_FETCH_SIZE $out/${tag}_fft_pmc_WRITE_SIZE | grep -E "fft" > $out/${tag}_fft_traffic.txt
+cat $out/${tag}_fft_traffic.txt

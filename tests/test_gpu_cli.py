@@ -26,18 +26,9 @@ def dev():
 
 
 def read_png(path):
-    data = open(path, "rb").read()
-    pos, idat, w, h = 8, b"", 0, 0
-    while pos < len(data):
-        n = int.from_bytes(data[pos:pos + 4], "big")
-        tag, body = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
-        if tag == b"IHDR":
-            w, h = int.from_bytes(body[:4], "big"), int.from_bytes(body[4:8], "big")
-        elif tag == b"IDAT":
-            idat += body
-        pos += 12 + n
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
-    return raw[:, 1:].reshape(h, w, 4).copy()
+    """RGBA pixels of a PNG (Pillow: mi_image_write encodes with stb_image_write, whose rows use every filter type)."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGBA")).copy()
 
 
 def run_tool(*args):

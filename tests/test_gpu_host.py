@@ -109,32 +109,23 @@ def test_run_ops_argument_errors(dev):
 
 
 def _png_pixels(path):
-    """Minimal reader for the PNGs mi_image_write produces (8-bit RGBA, filter 0, one IDAT)."""
+    """RGBA pixels of a PNG mi_image_write produced (the reference's encoder, stb_image_write: any filter type)."""
+    from PIL import Image
     data = open(path, "rb").read()
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, w, h = 8, b"", 0, 0
-    while pos < len(data):
-        n = int.from_bytes(data[pos:pos + 4], "big")
-        tag = data[pos + 4:pos + 8]
-        body = data[pos + 8:pos + 8 + n]
-        assert zlib.crc32(tag + body) == int.from_bytes(data[pos + 8 + n:pos + 12 + n], "big")
-        if tag == b"IHDR":
-            w, h = int.from_bytes(body[:4], "big"), int.from_bytes(body[4:8], "big")
-            assert body[8:] == bytes([8, 6, 0, 0, 0])
-        elif tag == b"IDAT":
-            idat += body
-        pos += 12 + n
-    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
-    assert (raw[:, 0] == 0).all()
-    return raw[:, 1:].reshape(h, w, 4)
+    return np.asarray(Image.open(path).convert("RGBA"))
 
 
 def test_config1_sample_image_gray_gauss_png(dev, golden, tmp_path):
     """BASELINE.json config 1: the reference's image/deer.jpeg (tests/golden/deer.jpeg, 2592x2000),
-    gray -> Gaussian 5x5 sigma 1.0 -> PNG.  JPEG decoding is host-side work outside the path
-    (stb_image upstream, Pillow here)."""
+    gray -> Gaussian 5x5 sigma 1.0 -> PNG.  The JPEG is decoded as the reference's loadImage decodes it --
+    stbi_load(..., STBI_rgb_alpha) of stb_image v2.30 (main.cpp:14), through the checker-side shim
+    oracle/stb_decode.c -- and the direct Gaussian (imageGaussianBlurWrapper's own form) must match the oracle
+    bit for bit; bench.py's c1 object times the same steps and prints the same CRC."""
+    import zlib as _z
+    import bench
     Image = pytest.importorskip("PIL.Image")
-    rgba = np.ascontiguousarray(np.asarray(Image.open(os.path.join(HERE, "golden", "deer.jpeg")).convert("RGBA")))
+    rgba = golden.stb_decode(os.path.join(HERE, "golden", "deer.jpeg"))
     h, w = rgba.shape[:2]
     assert (w, h) == (2592, 2000)
     loaded = np.empty_like(rgba)
@@ -145,6 +136,13 @@ def test_config1_sample_image_gray_gauss_png(dev, golden, tmp_path):
     ref = golden.gaussian(golden.grayscale(rgba, threads=8), 5, 1.0, threads=8)
     diff = np.abs(out.astype(np.int16) - ref.astype(np.int16))
     assert diff.max() <= 1
+    exact = np.empty_like(rgba)
+    ops.run_ops(exact, loaded, w, h, "gray,gauss_direct:5:1.0")
+    assert np.array_equal(exact, ref)
+    c1 = bench.leg_c1(ops)
+    assert c1["cpu"]["crc32_output"] == (_z.crc32(ref.tobytes()) & 0xffffffff)
+    assert c1["gpu_host_tier"]["crc32_output"] == (_z.crc32(out.tobytes()) & 0xffffffff)
+    assert c1["gpu_host_tier"]["direct_gaussian_bit_exact_vs_cpu"] and c1["gpu_host_tier"]["max_abs_diff_vs_cpu"] <= 1
     gray = np.empty_like(rgba)
     ops.imageGrayScaleWrapper(gray, loaded, w, h)
     assert np.array_equal(gray, golden.grayscale(rgba, threads=8))

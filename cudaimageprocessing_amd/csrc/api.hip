@@ -39,7 +39,7 @@ const Knob KNOBS[] = {
     {"MI_ROWS_PER_BAND", &Tuning::rows_per_band}, {"MI_CHAIN_ROWS_PER_BAND", &Tuning::chain_rows_per_band},
     {"MI_CHAIN_MARGIN", &Tuning::chain_margin}, {"MI_FFT_WAVES", &Tuning::fft_waves},
     {"MI_FFT_PERSISTENT", &Tuning::fft_persistent}, {"MI_FFT_PREFETCH", &Tuning::fft_prefetch},
-    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_TWOPASS_NT", &Tuning::fft_twopass_nt},
+    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_FUSED_SPECTRAL", &Tuning::fft_fused_spectral}, {"MI_FFT_TWOPASS_NT", &Tuning::fft_twopass_nt},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
     {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
@@ -676,6 +676,11 @@ int mi_fft_highpass_batch_u8x4_dev(const void* d_in, void* d_out, int w, int h, 
     if (overlap(d_workspace, need, d_in, img) || overlap(d_workspace, need, d_out, img))
         return fail(MI_ERR_OVERLAP, "workspace overlaps an image");
     hipStream_t s = (hipStream_t)stream;
+    if (w == h && fft_highpass_fused_supported(/*rows=*/w, /*cols=*/h)) {
+        // the two plane areas of the workspace; conversions and the filter ride on the transform's own passes
+        const size_t planes_bytes = up256((size_t)w * h * 8 * 3 * batch);
+        return launch_fft_highpass_fused(d_in, d_out, w, h, batch, w, h, cutoff, d_workspace, (char*)d_workspace + planes_bytes, s);
+    }
     return spectral_roundtrip_dev(d_in, d_out, w, h, batch, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
         return launch_highpass_unshifted(spectra, w, h, 3 * batch, cutoff, s);
     }, d_workspace, nullptr, s);
@@ -694,6 +699,21 @@ int mi_fft_highpass_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float cu
     // cufftPlan2d's first size is the slowest-varying dimension: the buffer is transformed as `width` rows
     // of `height` points, while the shift and the filter index it as `height` rows of `width`.  Square
     // images cannot tell; the reference's own 675x900 sample output is reproduced only this way.
+    if (w == h && fft_highpass_fused_supported(/*rows=*/w, /*cols=*/h)) {
+        int rc = check_image(in, out, w, h, 1);
+        if (rc) return rc;
+        const size_t n = (size_t)w * h, img_bytes = up256(n * 4), planes_bytes = up256(n * 8 * 3);
+        HostScratch scratch;
+        rc = host_scratch(img_bytes + 2 * planes_bytes, &scratch);
+        if (rc) return rc;
+        if (scratch.tables) *scratch.tables = HostScratch::TableKey{nullptr, 0, 0};      // this layout overwrites any chirp tables
+        char* d_img = (char*)scratch.ptr;
+        rc = host_upload(d_img, in, n * 4);
+        if (rc == MI_OK) rc = launch_fft_highpass_fused(d_img, d_img, w, h, 1, w, h, cutoff, d_img + img_bytes, d_img + img_bytes + planes_bytes, nullptr);
+        if (rc == MI_OK) rc = hip_status(hipStreamSynchronize(nullptr), "spectral round trip");
+        if (rc == MI_OK) rc = host_download(out, d_img, n * 4);
+        return rc;
+    }
     return spectral_roundtrip(in, out, w, h, /*rows=*/w, /*cols=*/h, [&](char* spectra) {
         // shift, filter, shift (imageTools.cu:704-737) as one pass over the three planes
         return launch_highpass_unshifted(spectra, w, h, 3, cutoff, nullptr);

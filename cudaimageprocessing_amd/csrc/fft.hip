@@ -527,6 +527,23 @@ static int twopass_launch(int threads, size_t lds, const c2* in, c2* out, const 
     return hip_status(hipGetLastError(), "fft kernel launch");
 }
 
+template <int NC, int RX, int R2, bool DIF, int IO>
+static int twopass_rows_io(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
+{
+    constexpr size_t lds = ((size_t)2 * (NC + NC / 16) + Plan8<NC>::tw_total) * sizeof(c2);
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    const i64 units = IO == IO_U8_OUT ? g.planes / 3 : g.planes;
+    return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, false, IO>>(NC / 8, lds, in, out, g, units * R2, s);
+}
+
+template <int R2, int RX, int NC, bool DIF>
+static int twopass_cols_gain(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
+{
+    constexpr int NCOL = 512 / (R2 / 32);
+    constexpr size_t lds = (size_t)(R2 + R2 / 32) * NCOL * 4 + (size_t)Plan32<R2>::tw_total * sizeof(c2);
+    return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false, true>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
+}
+
 template <int NC, int RX, int R2, bool DIF>
 static int twopass_rows(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
 {
@@ -546,6 +563,14 @@ static int twopass_cols(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t 
     return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
 }
 
+static TwoPassGeo twopass_geo(int rows, int cols, int planes, int dir)
+{
+    TwoPassGeo g{};
+    g.planes = planes; g.plane_stride = (i64)rows * cols; g.inverse = dir > 0;
+    g.xcd_remap = tuning().fft_twopass_remap; g.nt_stores = 0;
+    return g;
+}
+
 // sizes the two-pass plan is built for
 static bool twopass_supported(int rows, int cols)
 {
@@ -556,9 +581,8 @@ static bool twopass_supported(int rows, int cols)
 // out of place (src != dst), the rows pass works on its tile's own rows (src may equal dst).
 static int twopass_run(const c2* in, c2* mid, c2* out, int rows, int cols, int planes, int dir, int order, hipStream_t s)
 {
-    TwoPassGeo g;
-    g.planes = planes; g.plane_stride = (i64)rows * cols; g.inverse = dir > 0;
-    g.xcd_remap = tuning().fft_twopass_remap; g.nt_stores = tuning().fft_twopass_nt;
+    TwoPassGeo g = twopass_geo(rows, cols, planes, dir);
+    g.nt_stores = tuning().fft_twopass_nt;
     int rc;
     if (order == 0) {
         rc = twopass_cols<1024, 4, 4096, false>(in, mid, g, s);
@@ -568,6 +592,39 @@ static int twopass_run(const c2* in, c2* mid, c2* out, int rows, int cols, int p
         if (rc == MI_OK) rc = twopass_cols<1024, 4, 4096, true>(mid, out, g, s);
     }
     return rc;
+}
+
+// imageFFTImageGenerate's device core (imageTools.cu:633-791) with every pointwise step riding on a pass of the
+// two-pass plan: u8 -> complex on the loads of the forward rows pass, shift x gain x shift on the stores of the
+// forward cols pass, /N + saturate + pack on the stores of the inverse rows pass -- four passes over HBM per
+// image where the step-by-step form makes nine.  rows x cols = the geometry the transforms see (the
+// reference's: rows = w, cols = h); a, b: scratch of 3 * batch planes each.
+bool fft_highpass_fused_supported(int rows, int cols)
+{
+    return tuning().fft_twopass && tuning().fft_fused_spectral && twopass_supported(rows, cols);
+}
+
+int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
+                              void* a, void* b, hipStream_t s)
+{
+    // (the filter indexes the plane as h rows of w points: the plane's own geometry only when w == cols)
+    if (!fft_highpass_fused_supported(rows, cols) || w != cols || h != rows) return fail(MI_ERR_UNSUPPORTED, "fused spectral path: size %dx%d", rows, cols);
+    int rc = ensure_twiddles(s);
+    if (rc) return rc;
+    c2* A = (c2*)a;
+    c2* B = (c2*)b;
+    TwoPassGeo f = twopass_geo(rows, cols, 3 * batch, -1);
+    f.image_in = (const u32*)d_in;
+    rc = twopass_rows_io<4096, 4, 1024, true, IO_U8_IN>(A, A, f, s);               // images -> A (rows pass of the DIF order)
+    if (rc) return rc;
+    f.gain_h = h; f.cutoff = cutoff;
+    rc = twopass_cols_gain<1024, 4, 4096, true>(A, B, f, s);                        // A -> B: the filtered spectra, natural order
+    if (rc) return rc;
+    TwoPassGeo i = twopass_geo(rows, cols, 3 * batch, +1);
+    rc = twopass_cols<1024, 4, 4096, false>(B, A, i, s);                            // B -> A (cols pass of the DIT order)
+    if (rc) return rc;
+    i.image_out = (u32*)d_out; i.div = (float)(w * h);
+    return twopass_rows_io<4096, 4, 1024, false, IO_U8_OUT>(A, A, i, s);            // A -> images
 }
 
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s, void* tmp)

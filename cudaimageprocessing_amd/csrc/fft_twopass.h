@@ -91,6 +91,12 @@ struct TwoPassGeo {
     int planes;          // planes in this launch, back to back
     i64 plane_stride;    // points
     int inverse;
+    // the fused forms of imageFFTImageGenerate's pointwise steps (IO / GAIN template parameters):
+    const u32* image_in; // IO_U8_IN: RGBA images, plane p = channel p % 3 of image p / 3 (uchar4ToCufftComplex, imageTools.cu:506-515)
+    u32* image_out;      // IO_U8_OUT: the images written by the last rows pass (NormalizeAndZeroImaginary + ComplexRGBToUchar, :551-562, :517-527)
+    float div;           // IO_U8_OUT: the normalisation's divisor, (float)(w * h)
+    int gain_h;          // GAIN: rows of the image the filter sees (its width = the plane's row length: checked on the host)
+    float cutoff;        // GAIN: highpassFilter's cutoff (:530-549)
     int xcd_remap;       // 1: an XCD's blocks take a contiguous run of tiles
     int nt_stores;       // 1: non-temporal stores
 };
@@ -195,12 +201,35 @@ MI_DEV void rows_stages(c2 (&v)[RX][8], c2* __restrict__ lineA, c2* __restrict__
     }
 }
 
+constexpr int IO_COMPLEX = 0, IO_U8_IN = 1, IO_U8_OUT = 2;
+
+// ComplexRGBToUchar's cast with out-of-range values saturated (spectral.hip: sat_u8)
+MI_DEV u32 sat_u8_f(float v)
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 255.0f) return 255u;
+    return (u32)v;
+}
+
+// fftShift -> highpassFilter -> fftShift as one factor for the element at image coordinates (x, y) (spectral.hip:
+// highpass_unshifted_kernel; the same float expression, so the same bits): fftShift's swap, then the filter.
+MI_DEV int shifted_coord(int v, int n) { const int half = n / 2; return v < 2 * half ? (v < half ? v + half : v - half) : v; }
+MI_DEV float highpass_gain_xy(float cx, int y, int h, float cutoff)      // cx = (float)shifted x - w / 2.0f
+{
+    const float cy = (float)shifted_coord(y, h) - (float)h / 2.0f;
+    const float distance = sqrtf(cx * cx + cy * cy);
+    return 1.0f - expf(-(distance * distance) / (2.0f * cutoff * cutoff));
+}
+
 MI_DEV float flip_sign(float v, u32 mask) { return __uint_as_float(__float_as_uint(v) ^ mask); }
 
 // One tile = the RX rows r + R2*n1 (n1 < RX) of one plane; one block of NC/8 lanes per tile.
 // (All strides are compile-time: as run-time values the 32 scalar offsets of a tile's loads are
 // loop invariants that the compiler keeps live -- and spills -- across the whole tile loop.)
-template <int NC, int RX, int R2, bool DIF, bool NT>
+// IO: IO_COMPLEX = planes in, planes out; IO_U8_IN = the tile's points come from RGBA images (one channel per
+// plane, imaginary part 0); IO_U8_OUT = a block transforms the three colour planes of its image rows one after
+// the other and writes them as RGBA pixels, real part / div, saturated (planes = 3 x images then).
+template <int NC, int RX, int R2, bool DIF, bool NT, int IO = IO_COMPLEX>
 __global__ __launch_bounds__(NC / 8, (NC / 8 >= 512) ? 4 : 2)
 void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const TwoPassGeo g)
 {
@@ -230,35 +259,61 @@ void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Tw
         twr[i] = g_twiddle[idx];
     }
     constexpr int r2_log2 = __builtin_ctz(R2);
-    const int ntiles = g.planes << r2_log2;
+    constexpr int CH = IO == IO_U8_OUT ? 3 : 1;                    // planes a block works through
+    const int ntiles = (g.planes / CH) << r2_log2;
     constexpr u32 plane_bytes = (u32)((i64)RX * R2 * NC * 8);
     constexpr u32 row_group_bytes = (u32)R2 * NC * 8;              // between the RX rows of a tile
     constexpr int tw_rows = TW_N / (RX * R2);
     const u32 conj = g.inverse ? 0x80000000u : 0u;
-    {   // one tile per block
-        const int tile = g.xcd_remap ? xcd_contiguous_block() : (int)blockIdx.x;
-        if (tile >= ntiles) return;
-        const int plane = tile >> r2_log2, r = tile & (R2 - 1);
+    // one tile per block
+    const int tile = g.xcd_remap ? xcd_contiguous_block() : (int)blockIdx.x;
+    if (tile >= ntiles) return;
+    const int unit = tile >> r2_log2, r = tile & (R2 - 1);         // unit = plane, or image (IO_U8_OUT)
+    const u32 voff = ((u32)r * NC + (u32)t) * 8u;
+    // IO_U8_OUT: a finished channel's bytes, the RX rows of position k packed into one register; the loop over the
+    // three channels is a real loop (unrolled, the next plane's loads are hoisted above this plane's butterflies and
+    // the registers run out), so the finished channels shift along: at the end pk[0] = B, pk[1] = G, pk[2] = R
+    u32 pk[3][8] = {};
+#pragma unroll 1
+    for (int ch = 0; ch < CH; ch++) {
+        const int plane = unit * CH + ch;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + plane * g.plane_stride), 0, (int)plane_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + plane * g.plane_stride), 0, (int)plane_bytes, 0x00020000);
-        const u32 voff = ((u32)r * NC + (u32)t) * 8u;
         c2 v[RX][8];
+        if constexpr (IO == IO_U8_IN) {
+            // plane p = channel p % 3 of image p / 3; a pixel is 4 bytes where a point is 8
+            const int image = plane / 3, shift = 8 * (plane % 3);
+            const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)(g.image_in + (i64)image * (RX * R2) * NC), 0,
+                                                                                  (int)(plane_bytes / 2), 0x00020000);
+            u32 raw[RX][8];
 #pragma unroll
-        for (int n1 = 0; n1 < RX; n1++) {
+            for (int n1 = 0; n1 < RX; n1++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 8; k++) raw[n1][k] = __builtin_amdgcn_raw_buffer_load_b32(rimg, voff / 2, (n1 * row_group_bytes + (T * k) * 8) / 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n1 = 0; n1 < RX; n1++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[n1][k] = c2{(float)((raw[n1][k] >> shift) & 0xffu), 0.0f};
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < RX; n1++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
 #if MI_FFT2P_DBG == 2
-                const f32x2b x = f32x2b{(float)(t + tile + k), (float)(n1 - tile)};
+                    const f32x2b x = f32x2b{(float)(t + tile + k), (float)(n1 - tile)};
 #else
-                const f32x2b x = __builtin_bit_cast(f32x2b, (u32x2b)__builtin_amdgcn_raw_buffer_load_b64(rin, voff, n1 * row_group_bytes + (T * k) * 8, 0));
+                    const f32x2b x = __builtin_bit_cast(f32x2b, (u32x2b)__builtin_amdgcn_raw_buffer_load_b64(rin, voff, n1 * row_group_bytes + (T * k) * 8, 0));
 #endif
-                v[n1][k] = c2{x.x, x.y};
+                    v[n1][k] = c2{x.x, x.y};
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);      // every load is issued before anything waits for one
         }
-        __builtin_amdgcn_sched_barrier(0);      // every load is issued before anything waits for one
-        tw[t] = twr[0];
-        if (t + T < P::tw_total) tw[t + T] = twr[1];
-        __syncthreads();
+        if (ch == 0) {
+            tw[t] = twr[0];
+            if (t + T < P::tw_total) tw[t + T] = twr[1];
+        }
+        __syncthreads();       // (ch > 0: the previous plane's last stage reads no LDS; harmless)
 #pragma unroll
         for (int n1 = 0; n1 < RX; n1++) {
 #pragma unroll
@@ -281,15 +336,42 @@ void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Tw
             }
         }
         if constexpr (MI_FFT2P_DBG != 1) rows_stages<NC, RX>(v, lineA, lineB, tw, t);
-#pragma unroll
-        for (int n1 = 0; n1 < RX; n1++) {
+        if constexpr (IO == IO_U8_OUT) {
+            // NormalizeAndZeroImaginary + ComplexRGBToUchar: real part / div, saturated, one byte of the pixel
+            // (the conjugation of an inverse transform does not touch the real part)
+            static_assert(IO != IO_U8_OUT || RX <= 4, "one byte per row of the tile in a register");
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const c2 y = v[n1][k];
-                if (MI_FFT2P_DBG != 2 || y.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{y.x, flip_sign(y.y, conj)}), rout, voff,
-                                                      n1 * row_group_bytes + (T * k) * 8, NT ? 2 : 0);
+                u32 w = 0u;
+#pragma unroll
+                for (int n1 = 0; n1 < RX; n1++) w |= sat_u8_f(v[n1][k].x / g.div) << (8 * n1);
+                pk[2][k] = pk[1][k]; pk[1][k] = pk[0][k]; pk[0][k] = w;
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + plane * g.plane_stride), 0, (int)plane_bytes, 0x00020000);
+#pragma unroll
+            for (int n1 = 0; n1 < RX; n1++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const c2 y = v[n1][k];
+                    if (MI_FFT2P_DBG != 2 || y.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{y.x, flip_sign(y.y, conj)}), rout, voff,
+                                                          n1 * row_group_bytes + (T * k) * 8, NT ? 2 : 0);
+                }
             }
         }
+    }
+    if constexpr (IO == IO_U8_OUT) {
+        const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc((void*)(g.image_out + (i64)unit * (RX * R2) * NC), 0,
+                                                                              (int)(plane_bytes / 2), 0x00020000);
+#pragma unroll
+        for (int n1 = 0; n1 < RX; n1++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                // byte n1 of the three channel registers -> (R, G, B, 255)
+                const u32 rg = __builtin_amdgcn_perm(pk[1][k], pk[2][k], 0x0c0c0000u | (u32)n1 | ((u32)(4 + n1) << 8));
+                const u32 pixel = __builtin_amdgcn_perm(pk[0][k], rg, 0x0d000100u | ((u32)(4 + n1) << 16));
+                __builtin_amdgcn_raw_buffer_store_b32(pixel, rimg, voff / 2, (n1 * row_group_bytes + (T * k) * 8) / 2, 0);
+            }
     }
 }
 
@@ -368,7 +450,9 @@ MI_DEV void cols_stages(c2 (&v)[32], float* __restrict__ xl, const c2* __restric
 }
 
 // One tile = NCOL adjacent columns of one (plane, n1); one block of 512 lanes per tile.
-template <int R2, int RX, int NC, bool DIF, bool NT>
+// GAIN: every output is multiplied by the high-pass factor of its position (fftShift, highpassFilter, fftShift
+// of imageFFTImageGenerate, imageTools.cu:704-737, as one factor) on its way out.
+template <int R2, int RX, int NC, bool DIF, bool NT, bool GAIN = false>
 __global__ __launch_bounds__(512, 4)
 void fft2p_cols_kernel(const c2* __restrict__ in, c2* __restrict__ out, const TwoPassGeo g)
 {
@@ -433,8 +517,17 @@ void fft2p_cols_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Tw
         if constexpr (MI_FFT2P_DBG != 1) cols_stages<R2, NCOL>(v, xl, tw, c, t);
 #pragma unroll
         for (int k = 0; k < 32; k++) {
-            const c2 y = v[k];
-            if (MI_FFT2P_DBG != 2 || y.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{y.x, flip_sign(y.y, conj)}), rout, voff_out, k * out_step, NT ? 2 : 0);
+            c2 y = v[k];
+            y.y = flip_sign(y.y, conj);
+            if constexpr (GAIN) {
+                // the filter's geometry is the plane's own (the host checks: images as wide as the plane's rows are
+                // long), so a lane's column is its x and only y changes from point to point
+                const int x = cg * NCOL + c, row = (int)out_base + (t + T * k) * (int)out_stride;
+                const float gain = highpass_gain_xy((float)shifted_coord(x, NC) - (float)NC / 2.0f, row, g.gain_h, g.cutoff);
+                y.x *= gain; y.y *= gain;
+                if (k % 2 == 1) __builtin_amdgcn_sched_barrier(0);      // two factors at a time: 32 of them at once spill
+            }
+            if (MI_FFT2P_DBG != 2 || y.x == 1.2345e-30f) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2b, f32x2b{y.x, y.y}), rout, voff_out, k * out_step, NT ? 2 : 0);
         }
     }
 }

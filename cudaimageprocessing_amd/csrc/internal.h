@@ -27,6 +27,7 @@ struct Tuning {
     int fft_group_mib = 300;      // MI_FFT_GROUP_MIB: planes per Infinity-Cache group
     int fft_split = 1;            // MI_FFT_SPLIT
     int fft_twopass = 1;          // MI_FFT_TWOPASS: 4096x4096 planes in two passes per direction (fft_twopass.h); 2 = rows pass first where a third buffer allows
+    int fft_fused_spectral = 1;   // MI_FFT_FUSED_SPECTRAL: imageFFTImageGenerate's pointwise steps fused into the two-pass kernels
     int fft_twopass_group = 8;    // MI_FFT_TWOPASS_GROUP: planes per launch of the two-pass kernels
     int fft_twopass_remap = 1;    // MI_FFT_TWOPASS_REMAP: XCD-contiguous tiles
     int fft_twopass_nt = 0;       // MI_FFT_TWOPASS_NT: non-temporal stores
@@ -122,6 +123,10 @@ size_t fft2d_workspace_bytes(int rows, int cols);
 // tables_ready: the workspace still holds the chirp tables an earlier call built for these sizes
 int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, int dir, void* ws,
                      hipStream_t s, bool tables_ready = false);
+// the whole of imageFFTImageGenerate's device core in four passes over HBM (fft.hip; 4096 x 4096 today)
+bool fft_highpass_fused_supported(int rows, int cols);
+int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
+                              void* a, void* b, hipStream_t s);
 int launch_fftshift(void* d, int w, int h, hipStream_t s);
 int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s);
 int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);

@@ -273,6 +273,37 @@ def test_fft2d_4096_two_pass_plan_orders_groups_and_in_place(dev):
     assert torch.equal(fb[2], ops.fft2d(xb[2].contiguous()))
 
 
+def test_fft_highpass_4096_fused_passes_against_the_step_by_step_form(dev):
+    """imageFFTImageGenerate on 4096 x 4096 images: u8 -> complex rides on the loads of the forward rows pass, shift x
+    gain x shift on the stores of the forward cols pass, /N + saturate + pack on the stores of the inverse rows pass
+    (four passes over HBM instead of nine).  Same arithmetic per element -- the gain is the same float expression --
+    but the forward transform runs rows-then-cols where the step-by-step form runs cols-then-rows, so the floats
+    differ in the last bits and a value that sits on an integer may truncate one level apart: max |delta| 1 on
+    fewer than one byte in 10^5.  Device tier (batch of 2), host tier, and the step-by-step spectrum itself."""
+    n = 4096
+    img = np.stack([S.pattern_image("natural", n, n, 31), S.synth_image(32, n, n)])
+    d = torch.from_numpy(img).to(dev)
+    ws = torch.empty(ops.fft_highpass_workspace_bytes(n, n, 2), dtype=torch.uint8, device=dev)
+    assert ops.get_tuning("MI_FFT_FUSED_SPECTRAL") == 1
+    fused = ops.fft_highpass(d, 10.0, None, ws)
+    with ops.tuning(MI_FFT_FUSED_SPECTRAL=0):
+        steps = ops.fft_highpass(d, 10.0, None, ws)
+    diff = (fused.to(torch.int16) - steps.to(torch.int16)).abs()
+    assert int(diff.max()) <= 1
+    assert int((diff != 0).sum()) <= diff.numel() // 100000
+    assert bool((fused[..., 3] == 255).all())
+    assert torch.equal(ops.fft_highpass(d[1].contiguous(), 10.0), fused[1])      # a single image: the same kernels
+    # host tier (host buffers in and out, in place like the reference's demo)
+    host = img[0].copy()
+    ops.imageFFTImageGenerate(host, host, n, n)
+    assert np.array_equal(host, fused[0].cpu().numpy())
+    # independent of both: the spectrum route in double precision on one channel of a crop is out of reach at
+    # this size, so the gain itself is pinned instead -- the DC term is removed, the far corner untouched
+    flat = torch.full((n, n, 4), 200, dtype=torch.uint8, device=dev)
+    out = ops.fft_highpass(flat, 10.0)
+    assert int(out[..., :3].max()) == 0 and bool((out[..., 3] == 255).all())      # a constant image is all DC
+
+
 def test_pointwise_stages_match_oracle(dev, golden):
     img = S.synth_image(4, 96, 64)
     planes = ops.u8_to_complex(torch.from_numpy(img).to(dev))

@@ -731,6 +731,25 @@ int mi_compress_u8x4(const uint8_t* in, uint8_t* out, int w, int h, float keep_f
     if (!(keep_fraction > 0.0f) || !(keep_fraction <= 1.0f))
         return fail(MI_ERR_INVALID_ARG, "keep_fraction must be in (0, 1] (got %g)", (double)keep_fraction);
     const size_t n = (size_t)w * h;
+    if (w == h && fft_highpass_fused_supported(h, w)) {
+        // conversions on the transform's own first loads and last stores; the selection works on the spectra between
+        int rc = check_image(in, out, w, h, 1);
+        if (rc) return rc;
+        const size_t img_bytes = up256(n * 4), planes_bytes = up256(n * 8 * 3);
+        HostScratch scratch;
+        rc = host_scratch(img_bytes + 2 * planes_bytes, &scratch);
+        if (rc) return rc;
+        if (scratch.tables) *scratch.tables = HostScratch::TableKey{nullptr, 0, 0};
+        char* d_img = (char*)scratch.ptr;
+        char *a = d_img + img_bytes, *b = a + planes_bytes;
+        rc = host_upload(d_img, in, n * 4);
+        if (rc == MI_OK) rc = launch_spectral_fused_forward(d_img, w, h, 1, h, w, 0.0f, a, b, nullptr);
+        if (rc == MI_OK) rc = spectrum_keep_top(b, n, keep_count(n, keep_fraction), 3, nullptr);
+        if (rc == MI_OK) rc = launch_spectral_fused_inverse(d_img, w, h, 1, h, w, a, b, nullptr);
+        if (rc == MI_OK) rc = hip_status(hipStreamSynchronize(nullptr), "spectral round trip");
+        if (rc == MI_OK) rc = host_download(out, d_img, n * 4);
+        return rc;
+    }
     return spectral_roundtrip(in, out, w, h, /*rows=*/h, /*cols=*/w, [&](char* spectra) {
         return spectrum_keep_top(spectra, n, keep_count(n, keep_fraction), 3, nullptr);
     });

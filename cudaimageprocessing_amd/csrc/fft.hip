@@ -604,27 +604,42 @@ bool fft_highpass_fused_supported(int rows, int cols)
     return tuning().fft_twopass && tuning().fft_fused_spectral && twopass_supported(rows, cols);
 }
 
-int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
-                              void* a, void* b, hipStream_t s)
+// forward half: the images' colour planes -> their spectra in b (natural order), times the high-pass factor
+// when cutoff > 0; a: scratch of the same size
+int launch_spectral_fused_forward(const void* d_in, int w, int h, int batch, int rows, int cols, float cutoff,
+                                  void* a, void* b, hipStream_t s)
 {
     // (the filter indexes the plane as h rows of w points: the plane's own geometry only when w == cols)
     if (!fft_highpass_fused_supported(rows, cols) || w != cols || h != rows) return fail(MI_ERR_UNSUPPORTED, "fused spectral path: size %dx%d", rows, cols);
     int rc = ensure_twiddles(s);
     if (rc) return rc;
-    c2* A = (c2*)a;
-    c2* B = (c2*)b;
     TwoPassGeo f = twopass_geo(rows, cols, 3 * batch, -1);
     f.image_in = (const u32*)d_in;
-    rc = twopass_rows_io<4096, 4, 1024, true, IO_U8_IN>(A, A, f, s);               // images -> A (rows pass of the DIF order)
+    rc = twopass_rows_io<4096, 4, 1024, true, IO_U8_IN>((c2*)a, (c2*)a, f, s);               // images -> a (rows pass of the DIF order)
     if (rc) return rc;
-    f.gain_h = h; f.cutoff = cutoff;
-    rc = twopass_cols_gain<1024, 4, 4096, true>(A, B, f, s);                        // A -> B: the filtered spectra, natural order
-    if (rc) return rc;
+    if (cutoff > 0.0f) {
+        f.gain_h = h; f.cutoff = cutoff;
+        return twopass_cols_gain<1024, 4, 4096, true>((c2*)a, (c2*)b, f, s);                 // a -> b: the filtered spectra
+    }
+    return twopass_cols<1024, 4, 4096, true>((c2*)a, (c2*)b, f, s);
+}
+
+// inverse half: the spectra in b -> images (real part / (w h), saturated, alpha 255); a: scratch
+int launch_spectral_fused_inverse(void* d_out, int w, int h, int batch, int rows, int cols, void* a, void* b, hipStream_t s)
+{
+    if (!fft_highpass_fused_supported(rows, cols) || w != cols || h != rows) return fail(MI_ERR_UNSUPPORTED, "fused spectral path: size %dx%d", rows, cols);
     TwoPassGeo i = twopass_geo(rows, cols, 3 * batch, +1);
-    rc = twopass_cols<1024, 4, 4096, false>(B, A, i, s);                            // B -> A (cols pass of the DIT order)
+    int rc = twopass_cols<1024, 4, 4096, false>((c2*)b, (c2*)a, i, s);                       // b -> a (cols pass of the DIT order)
     if (rc) return rc;
     i.image_out = (u32*)d_out; i.div = (float)(w * h);
-    return twopass_rows_io<4096, 4, 1024, false, IO_U8_OUT>(A, A, i, s);            // A -> images
+    return twopass_rows_io<4096, 4, 1024, false, IO_U8_OUT>((c2*)a, (c2*)a, i, s);           // a -> images
+}
+
+int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
+                              void* a, void* b, hipStream_t s)
+{
+    const int rc = launch_spectral_fused_forward(d_in, w, h, batch, rows, cols, cutoff, a, b, s);
+    return rc ? rc : launch_spectral_fused_inverse(d_out, w, h, batch, rows, cols, a, b, s);
 }
 
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s, void* tmp)

@@ -127,6 +127,10 @@ int launch_fft2d_any(const void* in, void* out, int rows, int cols, int batch, i
 bool fft_highpass_fused_supported(int rows, int cols);
 int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
                               void* a, void* b, hipStream_t s);
+// the two halves separately (an edit of the spectra in `b` goes between them; cutoff <= 0: no filter)
+int launch_spectral_fused_forward(const void* d_in, int w, int h, int batch, int rows, int cols, float cutoff,
+                                  void* a, void* b, hipStream_t s);
+int launch_spectral_fused_inverse(void* d_out, int w, int h, int batch, int rows, int cols, void* a, void* b, hipStream_t s);
 int launch_fftshift(void* d, int w, int h, hipStream_t s);
 int launch_highpass(void* d, int w, int h, float cutoff, hipStream_t s);
 int launch_normalize_zero_imag(void* d, int w, int h, hipStream_t s);

@@ -39,7 +39,7 @@ const Knob KNOBS[] = {
     {"MI_ROWS_PER_BAND", &Tuning::rows_per_band}, {"MI_CHAIN_ROWS_PER_BAND", &Tuning::chain_rows_per_band},
     {"MI_CHAIN_MARGIN", &Tuning::chain_margin}, {"MI_FFT_WAVES", &Tuning::fft_waves},
     {"MI_FFT_PERSISTENT", &Tuning::fft_persistent}, {"MI_FFT_PREFETCH", &Tuning::fft_prefetch},
-    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_FUSED_SPECTRAL", &Tuning::fft_fused_spectral}, {"MI_FFT_TWOPASS_NT", &Tuning::fft_twopass_nt},
+    {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_FUSED_SPECTRAL", &Tuning::fft_fused_spectral},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
     {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},

@@ -527,42 +527,6 @@ static int twopass_launch(int threads, size_t lds, const c2* in, c2* out, const 
     return hip_status(hipGetLastError(), "fft kernel launch");
 }
 
-template <int NC, int RX, int R2, bool DIF, int IO>
-static int twopass_rows_io(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
-{
-    constexpr size_t lds = ((size_t)2 * (NC + NC / 16) + Plan8<NC>::tw_total) * sizeof(c2);
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
-    const i64 units = IO == IO_U8_OUT ? g.planes / 3 : g.planes;
-    return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, false, IO>>(NC / 8, lds, in, out, g, units * R2, s);
-}
-
-template <int R2, int RX, int NC, bool DIF>
-static int twopass_cols_gain(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
-{
-    constexpr int NCOL = 512 / (R2 / 32);
-    constexpr size_t lds = (size_t)(R2 + R2 / 32) * NCOL * 4 + (size_t)Plan32<R2>::tw_total * sizeof(c2);
-    return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false, true>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
-}
-
-template <int NC, int RX, int R2, bool DIF>
-static int twopass_rows(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
-{
-    constexpr size_t lds = ((size_t)2 * (NC + NC / 16) + Plan8<NC>::tw_total) * sizeof(c2);
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
-    if (g.nt_stores) return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, true>>(NC / 8, lds, in, out, g, (i64)g.planes * R2, s);
-    return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, false>>(NC / 8, lds, in, out, g, (i64)g.planes * R2, s);
-}
-
-template <int R2, int RX, int NC, bool DIF>
-static int twopass_cols(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
-{
-    constexpr int NCOL = 512 / (R2 / 32);
-    constexpr size_t lds = (size_t)(R2 + R2 / 32) * NCOL * 4 + (size_t)Plan32<R2>::tw_total * sizeof(c2);
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
-    if (g.nt_stores) return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, true>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
-    return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
-}
-
 static TwoPassGeo twopass_geo(int rows, int cols, int planes, int dir)
 {
     TwoPassGeo g{};
@@ -571,37 +535,105 @@ static TwoPassGeo twopass_geo(int rows, int cols, int planes, int dir)
     return g;
 }
 
-// sizes the two-pass plan is built for
-static bool twopass_supported(int rows, int cols)
+template <int NC, int RX, bool DIF, int IO = IO_COMPLEX>
+static int twopass_rows(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
 {
-    return rows == 4096 && cols == 4096;
+    constexpr int R2 = 1024;
+    constexpr size_t lds = ((size_t)2 * (NC + NC / 16) + Plan8<NC>::tw_total) * sizeof(c2);
+    static_assert(lds <= 80 * 1024, "at least two blocks per CU");
+    const i64 units = IO == IO_U8_OUT ? g.planes / 3 : g.planes;
+    return twopass_launch<fft2p_rows_kernel<NC, RX, R2, DIF, false, IO>>(NC / 8, lds, in, out, g, units * R2, s);
 }
 
-// order: 0 = cols pass then rows pass (DIT), 1 = rows pass then cols pass (DIF).  The cols pass is
-// out of place (src != dst), the rows pass works on its tile's own rows (src may equal dst).
-static int twopass_run(const c2* in, c2* mid, c2* out, int rows, int cols, int planes, int dir, int order, hipStream_t s)
+template <int RX, int NC, bool DIF, bool GAIN = false>
+static int twopass_cols(const c2* in, c2* out, const TwoPassGeo& g, hipStream_t s)
 {
-    TwoPassGeo g = twopass_geo(rows, cols, planes, dir);
-    g.nt_stores = tuning().fft_twopass_nt;
+    constexpr int R2 = 1024, NCOL = 512 / (R2 / 32);
+    constexpr size_t lds = (size_t)(R2 + R2 / 32) * NCOL * 4 + (size_t)Plan32<R2>::tw_total * sizeof(c2);
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    return twopass_launch<fft2p_cols_kernel<R2, RX, NC, DIF, false, GAIN>>(512, lds, in, out, g, (i64)g.planes * RX * (NC / NCOL), s);
+}
+
+// Sizes the two-pass plan is built for: 1024-point column tiles, so rows = RX * 1024 with RX = 1, 2 or 4 (RX rows of
+// `cols` points = at most 16 Ki points a rows-pass tile), and the row lengths the rows pass is instantiated for.
+// rows = 1024 needs no rows pass of this kind (nothing to combine across rows): its cols pass works on its own rows,
+// in place if asked, and the ordinary row transform follows.
+static bool twopass_supported(int rows, int cols)
+{
+    return (rows == 1024 || rows == 2048 || rows == 4096) && (cols == 1024 || cols == 2048 || cols == 4096);
+}
+
+// the ordinary row transform of `planes` planes (fft_lines_kernel), in launches of less than 2 GiB
+static int plain_rows_pass(const c2* in, c2* out, int rows, int cols, int planes, int dir, hipStream_t s);
+
+// order: 0 = cols pass then rows pass (DIT), 1 = rows pass then cols pass (DIF).  The cols pass is out of place
+// (src != dst) unless RX == 1, the rows pass works on its tile's own rows (src may equal dst).
+template <int NC, int RX>
+static int twopass_run_t(const c2* in, c2* mid, c2* out, int rows, int planes, int dir, int order, hipStream_t s)
+{
+    const TwoPassGeo g = twopass_geo(rows, NC, planes, dir);
     int rc;
-    if (order == 0) {
-        rc = twopass_cols<1024, 4, 4096, false>(in, mid, g, s);
-        if (rc == MI_OK) rc = twopass_rows<4096, 4, 1024, false>(mid, out, g, s);
+    if constexpr (RX == 1) {
+        if (order == 0) {
+            rc = twopass_cols<1, NC, false>(in, mid, g, s);
+            if (rc == MI_OK) rc = plain_rows_pass(mid, out, rows, NC, planes, dir, s);
+        } else {
+            rc = plain_rows_pass(in, mid, rows, NC, planes, dir, s);
+            if (rc == MI_OK) rc = twopass_cols<1, NC, false>(mid, out, g, s);
+        }
+    } else if (order == 0) {
+        rc = twopass_cols<RX, NC, false>(in, mid, g, s);
+        if (rc == MI_OK) rc = twopass_rows<NC, RX, false>(mid, out, g, s);
     } else {
-        rc = twopass_rows<4096, 4, 1024, true>(in, mid, g, s);
-        if (rc == MI_OK) rc = twopass_cols<1024, 4, 4096, true>(mid, out, g, s);
+        rc = twopass_rows<NC, RX, true>(in, mid, g, s);
+        if (rc == MI_OK) rc = twopass_cols<RX, NC, true>(mid, out, g, s);
     }
     return rc;
+}
+
+static int twopass_run(const c2* in, c2* mid, c2* out, int rows, int cols, int planes, int dir, int order, hipStream_t s)
+{
+#define MI_TP(NC_, RX_) if (cols == NC_ && rows == RX_ * 1024) return twopass_run_t<NC_, RX_>(in, mid, out, rows, planes, dir, order, s);
+    MI_TP(1024, 1) MI_TP(1024, 2) MI_TP(1024, 4) MI_TP(2048, 1) MI_TP(2048, 2) MI_TP(2048, 4) MI_TP(4096, 1) MI_TP(4096, 2) MI_TP(4096, 4)
+#undef MI_TP
+    return fail(MI_ERR_UNSUPPORTED, "two-pass plan: size %dx%d", rows, cols);
 }
 
 // imageFFTImageGenerate's device core (imageTools.cu:633-791) with every pointwise step riding on a pass of the
 // two-pass plan: u8 -> complex on the loads of the forward rows pass, shift x gain x shift on the stores of the
 // forward cols pass, /N + saturate + pack on the stores of the inverse rows pass -- four passes over HBM per
 // image where the step-by-step form makes nine.  rows x cols = the geometry the transforms see (the
-// reference's: rows = w, cols = h); a, b: scratch of 3 * batch planes each.
+// reference's: rows = w, cols = h); a, b: scratch of 3 * batch planes each.  Square images of 2048 or 4096 pixels
+// a side (1024 has no rows pass of this kind to carry the conversions).
 bool fft_highpass_fused_supported(int rows, int cols)
 {
-    return tuning().fft_twopass && tuning().fft_fused_spectral && twopass_supported(rows, cols);
+    return tuning().fft_twopass && tuning().fft_fused_spectral && rows == cols && (rows == 2048 || rows == 4096);
+}
+
+template <int N>
+static int spectral_fused_forward_t(const void* d_in, int batch, float cutoff, void* a, void* b, hipStream_t s)
+{
+    constexpr int RX = N / 1024;
+    TwoPassGeo f = twopass_geo(N, N, 3 * batch, -1);
+    f.image_in = (const u32*)d_in;
+    int rc = twopass_rows<N, RX, true, IO_U8_IN>((c2*)a, (c2*)a, f, s);                 // images -> a (rows pass of the DIF order)
+    if (rc) return rc;
+    if (cutoff > 0.0f) {
+        f.gain_h = N; f.cutoff = cutoff;
+        return twopass_cols<RX, N, true, true>((c2*)a, (c2*)b, f, s);                 // a -> b: the filtered spectra
+    }
+    return twopass_cols<RX, N, true>((c2*)a, (c2*)b, f, s);
+}
+
+template <int N>
+static int spectral_fused_inverse_t(void* d_out, int batch, void* a, void* b, hipStream_t s)
+{
+    constexpr int RX = N / 1024;
+    TwoPassGeo i = twopass_geo(N, N, 3 * batch, +1);
+    int rc = twopass_cols<RX, N, false>((c2*)b, (c2*)a, i, s);                         // b -> a (cols pass of the DIT order)
+    if (rc) return rc;
+    i.image_out = (u32*)d_out; i.div = (float)(N * N);
+    return twopass_rows<N, RX, false, IO_U8_OUT>((c2*)a, (c2*)a, i, s);                // a -> images
 }
 
 // forward half: the images' colour planes -> their spectra in b (natural order), times the high-pass factor
@@ -611,28 +643,16 @@ int launch_spectral_fused_forward(const void* d_in, int w, int h, int batch, int
 {
     // (the filter indexes the plane as h rows of w points: the plane's own geometry only when w == cols)
     if (!fft_highpass_fused_supported(rows, cols) || w != cols || h != rows) return fail(MI_ERR_UNSUPPORTED, "fused spectral path: size %dx%d", rows, cols);
-    int rc = ensure_twiddles(s);
+    const int rc = ensure_twiddles(s);
     if (rc) return rc;
-    TwoPassGeo f = twopass_geo(rows, cols, 3 * batch, -1);
-    f.image_in = (const u32*)d_in;
-    rc = twopass_rows_io<4096, 4, 1024, true, IO_U8_IN>((c2*)a, (c2*)a, f, s);               // images -> a (rows pass of the DIF order)
-    if (rc) return rc;
-    if (cutoff > 0.0f) {
-        f.gain_h = h; f.cutoff = cutoff;
-        return twopass_cols_gain<1024, 4, 4096, true>((c2*)a, (c2*)b, f, s);                 // a -> b: the filtered spectra
-    }
-    return twopass_cols<1024, 4, 4096, true>((c2*)a, (c2*)b, f, s);
+    return rows == 4096 ? spectral_fused_forward_t<4096>(d_in, batch, cutoff, a, b, s) : spectral_fused_forward_t<2048>(d_in, batch, cutoff, a, b, s);
 }
 
 // inverse half: the spectra in b -> images (real part / (w h), saturated, alpha 255); a: scratch
 int launch_spectral_fused_inverse(void* d_out, int w, int h, int batch, int rows, int cols, void* a, void* b, hipStream_t s)
 {
     if (!fft_highpass_fused_supported(rows, cols) || w != cols || h != rows) return fail(MI_ERR_UNSUPPORTED, "fused spectral path: size %dx%d", rows, cols);
-    TwoPassGeo i = twopass_geo(rows, cols, 3 * batch, +1);
-    int rc = twopass_cols<1024, 4, 4096, false>((c2*)b, (c2*)a, i, s);                       // b -> a (cols pass of the DIT order)
-    if (rc) return rc;
-    i.image_out = (u32*)d_out; i.div = (float)(w * h);
-    return twopass_rows_io<4096, 4, 1024, false, IO_U8_OUT>((c2*)a, (c2*)a, i, s);           // a -> images
+    return rows == 4096 ? spectral_fused_inverse_t<4096>(d_out, batch, a, b, s) : spectral_fused_inverse_t<2048>(d_out, batch, a, b, s);
 }
 
 int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int batch, int rows, int cols, float cutoff,
@@ -642,11 +662,28 @@ int launch_fft_highpass_fused(const void* d_in, void* d_out, int w, int h, int b
     return rc ? rc : launch_spectral_fused_inverse(d_out, w, h, batch, rows, cols, a, b, s);
 }
 
+static int plain_rows_pass(const c2* in, c2* out, int rows, int cols, int planes, int dir, hipStream_t s)
+{
+    const i64 plane = (i64)rows * cols;
+    const int group = (int)std::max<i64>(1, std::min<i64>((((i64)1 << 31) - 1) / (plane * 8), ((i64)1 << 30) / rows));
+    for (int b0 = 0; b0 < planes; b0 += group) {
+        const int nb = std::min(group, planes - b0);
+        FftGeo row;
+        row.inverse = dir > 0; row.plane_stride = plane; row.tw_step = 0; row.tw_uniform = 0;
+        row.inner_log2 = 0; row.groups_log2 = __builtin_ctz(rows); row.total_lines = rows * nb; row.line_stride = 0;
+        row.in_group_stride = row.out_group_stride = cols;
+        row.in_elem_stride = row.out_elem_stride = 1;
+        const int rc = launch_pass<false>(cols, in + (i64)b0 * plane, out + (i64)b0 * plane, row, (u32)((i64)nb * plane * 8), s);
+        if (rc) return rc;
+    }
+    return MI_OK;
+}
+
 int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int dir, hipStream_t s, void* tmp)
 {
     int rc = ensure_twiddles(s);
     if (rc) return rc;
-    if (tuning().fft_twopass && twopass_supported(rows, cols) && (in != out || tmp != nullptr)) {
+    if (tuning().fft_twopass && twopass_supported(rows, cols) && (in != out || tmp != nullptr || rows == 1024)) {
         const i64 plane = (i64)rows * cols;
         const int order = tuning().fft_twopass == 2 ? 1 : 0;
         if (in != out) {
@@ -654,7 +691,8 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
             // thousand tiles pays for its ramp-up and tail (2 planes per launch: 4.0 ms per round trip of
             // 16 planes; 8 or 16: 3.5 ms), which is worth more than finding the first pass's output
             // in the Infinity Cache.
-            const int group = std::max(1, tuning().fft_twopass_group);
+            // (the knob counts 4096 x 4096 planes: the same bytes per launch for smaller ones)
+            const int group = std::max(1, tuning().fft_twopass_group * (int)(((i64)4096 * 4096) / plane));
             for (int b0 = 0; b0 < batch; b0 += group) {
                 const int nb = std::min(group, batch - b0);
                 const c2* pin = (const c2*)in + (i64)b0 * plane;
@@ -665,6 +703,13 @@ int launch_fft2d(const void* in, void* out, int rows, int cols, int batch, int d
                     for (int b = 0; b < nb && rc == MI_OK; b++)
                         rc = twopass_run(pin + b * plane, (c2*)tmp, pout + b * plane, rows, cols, 1, dir, 1, s);
                 }
+                if (rc) return rc;
+            }
+        } else if (rows == 1024) {                 // the cols pass of a 1024-row plane works on its own rows: in place
+            const int group = std::max(1, tuning().fft_twopass_group * (int)(((i64)4096 * 4096) / plane));
+            for (int b0 = 0; b0 < batch; b0 += group) {
+                c2* p = (c2*)out + (i64)b0 * plane;
+                rc = twopass_run(p, p, p, rows, cols, std::min(group, batch - b0), dir, 0, s);
                 if (rc) return rc;
             }
         } else {

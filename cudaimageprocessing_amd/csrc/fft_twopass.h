@@ -230,7 +230,7 @@ MI_DEV float flip_sign(float v, u32 mask) { return __uint_as_float(__float_as_ui
 // plane, imaginary part 0); IO_U8_OUT = a block transforms the three colour planes of its image rows one after
 // the other and writes them as RGBA pixels, real part / div, saturated (planes = 3 x images then).
 template <int NC, int RX, int R2, bool DIF, bool NT, int IO = IO_COMPLEX>
-__global__ __launch_bounds__(NC / 8, (NC / 8 >= 512) ? 4 : 2)
+__global__ __launch_bounds__(NC / 8, 4)
 void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const TwoPassGeo g)
 {
     constexpr int T = NC / 8;
@@ -244,10 +244,10 @@ void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Tw
     // Base twiddles of stages 1..: W_(R NS)^k, k < NS -- entry e of the block's table, e = t and t + T.
     // Their loads are issued BEFORE the tile's (they come back first: vector-memory operations
     // complete in order) and go to LDS after the tile's loads are on their way.
-    static_assert(P::tw_total <= 2 * T, "two table entries per lane");
-    c2 twr[2];
+    constexpr int NTW = (P::tw_total + T - 1) / T;         // table entries per lane (2 for 4096 points, 5 for 1024)
+    c2 twr[NTW];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NTW; i++) {
         const int e = t + T * i;
         int off = 0, ns = 1, idx = 0;
 #pragma unroll
@@ -310,8 +310,9 @@ void fft2p_rows_kernel(const c2* __restrict__ in, c2* __restrict__ out, const Tw
             __builtin_amdgcn_sched_barrier(0);      // every load is issued before anything waits for one
         }
         if (ch == 0) {
-            tw[t] = twr[0];
-            if (t + T < P::tw_total) tw[t + T] = twr[1];
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+                if (t + T * i < P::tw_total) tw[t + T * i] = twr[i];
         }
         __syncthreads();       // (ch > 0: the previous plane's last stage reads no LDS; harmless)
 #pragma unroll

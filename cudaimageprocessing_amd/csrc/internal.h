@@ -30,7 +30,6 @@ struct Tuning {
     int fft_fused_spectral = 1;   // MI_FFT_FUSED_SPECTRAL: imageFFTImageGenerate's pointwise steps fused into the two-pass kernels
     int fft_twopass_group = 8;    // MI_FFT_TWOPASS_GROUP: planes per launch of the two-pass kernels
     int fft_twopass_remap = 1;    // MI_FFT_TWOPASS_REMAP: XCD-contiguous tiles
-    int fft_twopass_nt = 0;       // MI_FFT_TWOPASS_NT: non-temporal stores
     int fft_chirpz_blocks_per_cu = 2;   // MI_FFT_CHIRPZ_BLOCKS_PER_CU
     int fft_fused_chirpz = 1;     // MI_FFT_FUSED_CHIRPZ
     int png_zlib = 0;             // MI_PNG_ZLIB: mi_image_write encodes with zlib instead of the reference's stb_image_write

@@ -273,6 +273,45 @@ def test_fft2d_4096_two_pass_plan_orders_groups_and_in_place(dev):
     assert torch.equal(fb[2], ops.fft2d(xb[2].contiguous()))
 
 
+@pytest.mark.parametrize("rows,cols", [(1024, 1024), (2048, 2048), (1024, 4096), (4096, 1024), (2048, 4096), (4096, 2048), (1024, 2048), (2048, 1024)])
+def test_fft2d_two_pass_plan_at_every_size_it_is_built_for(dev, rows, cols):
+    """The two-pass plan covers rows, cols in {1024, 2048, 4096} (column tiles of 1024 points, RX = rows / 1024
+    rows combined per rows-pass tile; rows = 1024 pairs the cols pass with the ordinary row transform).  Both
+    orders, forward and inverse, in place with and -- for 1024 rows -- without a workspace, a batch of 3 in
+    partial launch groups, against numpy.fft in double precision and the three-pass plan."""
+    x0 = rand_plane(rows, cols, rows + cols)
+    ref_f = np.fft.fft2(x0.astype(np.complex128))
+    ref_i = np.fft.ifft2(x0.astype(np.complex128)) * float(rows * cols)
+    xd = torch.from_numpy(x0).to(dev)
+    ws = torch.empty(ops.fft2d_workspace_bytes(rows, cols), dtype=torch.uint8, device=dev)
+    out = {}
+    for mode in (0, 1, 2):
+        with ops.tuning(MI_FFT_TWOPASS=mode):
+            f = ops.fft2d(xd)
+            assert rel_l2(f.cpu().numpy(), ref_f) <= REL_L2, mode
+            assert rel_l2(ops.fft2d(xd, inverse=True).cpu().numpy(), ref_i) <= REL_L2, mode
+            y = xd.clone()
+            ops.fft2d(y, out=y, workspace=ws)
+            assert rel_l2(y.cpu().numpy(), ref_f) <= REL_L2, mode
+            g = torch.empty_like(xd)
+            _lib.check(_lib.lib().mi_fft2d_c2c_f32_ws_dev(xd.data_ptr(), g.data_ptr(), rows, cols, 1, _lib.FFT_INVERSE,
+                                                          ws.data_ptr(), ws.numel(), None))
+            torch.cuda.synchronize()
+            assert rel_l2(g.cpu().numpy(), ref_i) <= REL_L2, mode
+            out[mode] = f
+    y = xd.clone()
+    ops.fft2d(y, out=y)                                                 # in place, no workspace
+    assert rel_l2(y.cpu().numpy(), ref_f) <= REL_L2
+    if rows == 1024:
+        assert torch.equal(y, out[1])                                   # the cols pass on its own rows: the same kernels
+    xb = torch.stack([xd, xd.flip(1), xd * 0.25])
+    with ops.tuning(MI_FFT_TWOPASS_GROUP=1):                            # (the knob counts 4096 x 4096 planes)
+        fb = ops.fft2d(xb)
+    fb8 = ops.fft2d(xb)
+    assert torch.equal(fb, fb8) and torch.equal(fb[0], out[1])
+    assert rel_l2(fb[1].cpu().numpy(), np.fft.fft2(x0[:, ::-1].astype(np.complex128))) <= REL_L2
+
+
 def test_fft_highpass_4096_fused_passes_against_the_step_by_step_form(dev):
     """imageFFTImageGenerate on 4096 x 4096 images: u8 -> complex rides on the loads of the forward rows pass, shift x
     gain x shift on the stores of the forward cols pass, /N + saturate + pack on the stores of the inverse rows pass
@@ -302,6 +341,36 @@ def test_fft_highpass_4096_fused_passes_against_the_step_by_step_form(dev):
     flat = torch.full((n, n, 4), 200, dtype=torch.uint8, device=dev)
     out = ops.fft_highpass(flat, 10.0)
     assert int(out[..., :3].max()) == 0 and bool((out[..., 3] == 255).all())      # a constant image is all DC
+
+
+def test_fft_highpass_2048_fused_passes_against_the_step_by_step_form_and_the_oracle_gain(dev, golden):
+    """The same fusion at 2048 x 2048 (RX = 2), where one channel is still in reach of a double-precision check:
+    numpy fft2 -> the oracle's gain table -> ifft2 -> truncate, against channel 0 of the fused output."""
+    n = 2048
+    img = np.stack([S.pattern_image("natural", n, n, 41), S.synth_image(42, n, n), S.pattern_image("checker", n, n, 43)])
+    d = torch.from_numpy(img).to(dev)
+    ws = torch.empty(ops.fft_highpass_workspace_bytes(n, n, 3), dtype=torch.uint8, device=dev)
+    fused = ops.fft_highpass(d, 10.0, None, ws)
+    with ops.tuning(MI_FFT_FUSED_SPECTRAL=0):
+        steps = ops.fft_highpass(d, 10.0, None, ws)
+    diff = (fused.to(torch.int16) - steps.to(torch.int16)).abs()
+    assert int(diff.max()) <= 1
+    assert int((diff != 0).sum()) <= diff.numel() // 100000
+    assert bool((fused[..., 3] == 255).all())
+    host = img[1].copy()
+    ops.imageFFTImageGenerate(host, host, n, n)
+    assert np.array_equal(host, fused[1].cpu().numpy())
+    # double precision, one channel: gain in the shifted frame = distance from the centre (imageTools.cu:703-719)
+    x = img[0][..., 0].astype(np.float64)
+    yy, xx = np.meshgrid(np.arange(n) - n // 2, np.arange(n) - n // 2, indexing="ij")
+    gain = 1.0 - np.exp(-(xx * xx + yy * yy) / (2.0 * 10.0 * 10.0))
+    spec = np.fft.fftshift(np.fft.fft2(x)) * gain
+    back = np.fft.ifft2(np.fft.ifftshift(spec)).real
+    want = np.clip(np.trunc(back), 0, 255)
+    got = fused[0, ..., 0].cpu().numpy().astype(np.float64)
+    near_integer = np.abs(back - np.round(back)) < 2e-3                  # fp32 pipeline: ties at integers may fall either way
+    assert np.abs(got - want)[~near_integer].max() == 0
+    assert np.abs(got - want).max() <= 1
 
 
 def test_pointwise_stages_match_oracle(dev, golden):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""4096x4096 planes: the two-pass plan (fft_twopass.h) against the three-pass plan and numpy.fft,
-then the timing of both.  Usage: python tools/check_twopass.py [batch]"""
+"""rows x cols planes (1024, 2048 or 4096 each): the two-pass plan (fft_twopass.h) against the three-pass plan
+and numpy.fft, then the timing of both.  Usage: python tools/check_twopass.py [batch [rows cols]]"""
 import os
 import sys
 import time
@@ -12,9 +12,10 @@ import torch  # noqa: E402
 from cudaimageprocessing_amd import ops  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-n = 4096
+rows = int(sys.argv[2]) if len(sys.argv) > 3 else 4096
+cols = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 rng = np.random.default_rng(1)
-x0 = (rng.uniform(0, 255, (n, n)) + 1j * rng.uniform(-50, 50, (n, n))).astype(np.complex64)
+x0 = (rng.uniform(0, 255, (rows, cols)) + 1j * rng.uniform(-50, 50, (rows, cols))).astype(np.complex64)
 xd = torch.from_numpy(x0).cuda()
 
 
@@ -25,18 +26,18 @@ def rel(a, b):
 
 t0 = time.time()
 ref = np.fft.fft2(x0.astype(np.complex128))
-refi = np.fft.ifft2(x0.astype(np.complex128)) * (n * n)
-print(f"numpy reference {time.time() - t0:.1f} s", flush=True)
+refi = np.fft.ifft2(x0.astype(np.complex128)) * (rows * cols)
+print(f"{rows} x {cols}: numpy reference {time.time() - t0:.1f} s", flush=True)
 for mode in (0, 1, 2):
     with ops.tuning(MI_FFT_TWOPASS=mode, restore={"MI_FFT_TWOPASS": 1}):
         f = ops.fft2d(xd).cpu().numpy()
         i = ops.fft2d(xd, inverse=True).cpu().numpy()
         y = xd.clone()
-        ws = torch.empty(ops.fft2d_workspace_bytes(n, n), dtype=torch.uint8, device="cuda")
+        ws = torch.empty(ops.fft2d_workspace_bytes(rows, cols), dtype=torch.uint8, device="cuda")
         ops.fft2d(y, out=y, workspace=ws)
         print(f"MI_FFT_TWOPASS={mode}: forward rel-L2 {rel(f, ref):.2e}, inverse {rel(i, refi):.2e}, in place {rel(y.cpu().numpy(), ref):.2e}", flush=True)
 
-gray = ops.synth(5, n, n * batch)[..., 0].to(torch.float32).reshape(batch, n, n)
+gray = ops.synth(5, cols, rows * batch)[..., 0].to(torch.float32).reshape(batch, rows, cols)
 x = torch.complex(gray, torch.zeros_like(gray))
 f = torch.empty_like(x)
 y = torch.empty_like(x)
@@ -55,7 +56,7 @@ def timed(fn, reps=5):
     return a.elapsed_time(b) / reps
 
 
-px = batch * n * n
+px = batch * rows * cols
 for mode in (0, 1, 0, 1):
     with ops.tuning(MI_FFT_TWOPASS=mode, restore={"MI_FFT_TWOPASS": 1}):
         fwd = timed(lambda: ops.fft2d(x, out=f))

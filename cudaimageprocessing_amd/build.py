@@ -7,7 +7,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libmi_imagetools.so")
 
-SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "noalloc.hip", "strips.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
+SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "gauss_direct.hip", "noalloc.hip", "strips.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
 HEADERS = ["common.h", "internal.h", "median5_network.h", "fft_twopass.h",
            os.path.join("..", "..", "include", "mi_imagetools.h"),
            os.path.join("..", "..", "include", "imageTools.h")]
@@ -26,7 +26,8 @@ FLAGS += shlex.split(os.environ.get("MI_EXTRA_CXXFLAGS", ""))
 # Per-file flags.  fft.hip: the SLP vectoriser pairs the butterflies' scalar fp32 operations into v_pk_* ones --
 # which issue at the scalar rate on this part -- and pays for it in register shuffles (198 v_mov in the cols
 # kernel of the two-pass plan, 128 registers with spills to scratch; without it 85 registers, no spills).
-FILE_FLAGS = {"fft.hip": ["-fno-slp-vectorize"]}
+# gauss_direct.hip: the same for the multiply-add chains of the direct Gaussians (see the head of that file).
+FILE_FLAGS = {"fft.hip": ["-fno-slp-vectorize"], "gauss_direct.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale():

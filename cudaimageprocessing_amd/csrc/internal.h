@@ -35,6 +35,7 @@ struct Tuning {
     int png_zlib = 0;             // MI_PNG_ZLIB: mi_image_write encodes with zlib instead of the reference's stb_image_write
     int mean_prefix = 1;          // MI_MEAN_PREFIX: mean 17x17..31x31 as a wave march on prefix sums (0: LDS tiles)
     int host_copy_threads = 4;    // MI_HOST_COPY_THREADS: host threads per direction that stage a chunk between pageable and pinned memory
+    int gauss_direct_win = 1;     // MI_GAUSS_DIRECT_WIN: direct Gaussians 5x5 / 7x7 from gauss_direct.hip (0: round 2's march kernel; same bits)
     int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
     int lds_pad_kib = 24;         // MI_LDS_PAD_KIB: extra LDS per block of the 3x3 march kernels (20 + 24 KiB: three blocks per CU, +2.5 %)
     int sep_lds_pad_kib = -1;     // MI_SEP_LDS_PAD_KIB: the same for the separable Gaussian (5x5) and mean kernels (-1: by kernel size)

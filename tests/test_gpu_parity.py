@@ -163,6 +163,29 @@ def test_gaussian_direct_is_bit_exact(dev, golden, k, sigma):
         assert np.array_equal(got, golden.gaussian(img, k, sigma))
 
 
+@pytest.mark.parametrize("k,sigma", [(5, 1.0), (5, 0.3), (5, 40.0), (7, 1.5), (7, 0.4)])
+def test_gaussian_direct_5_and_7_packed_pairs_and_round_2_kernel_agree_with_the_oracle(dev, golden, k, sigma):
+    """5x5 and 7x7 come from csrc/gauss_direct.hip: 5x5 with its window as float pairs ((red, green) of a pixel,
+    blue of pixels two columns apart) feeding v_pk_fma_f32, 7x7 with per-step conversions and vector-register
+    weights.  Each half of a packed multiply-add is the scalar operation, so the bytes are the oracle's; round 2's
+    kernel (MI_GAUSS_DIRECT_WIN=0) stays as a second implementation of the same sums.  Aligned (buffer addressing)
+    and odd widths, bands that end mid-window, a batch, the structured patterns."""
+    assert ops.get_tuning("MI_GAUSS_DIRECT_WIN") == 1
+    for (w, h, pattern) in ((640, 61, None), (517, 73, None), (259, 40, "checker"), (1024, 33, "natural"), (8, 9, None), (300, 7, "impulse")):
+        img = S.synth_image(7 * k + w, w, h) if pattern is None else S.pattern_image(pattern, w, h, k)
+        want = golden.gaussian(img, k, sigma, threads=8)
+        d = to_dev(img, dev)
+        assert np.array_equal(host(ops.gaussian_blur(d, k, sigma, direct=True)), want), (w, h, "new")
+        with ops.tuning(MI_GAUSS_DIRECT_WIN=0):
+            assert np.array_equal(host(ops.gaussian_blur(d, k, sigma, direct=True)), want), (w, h, "round 2")
+        with ops.tuning(MI_ROWS_PER_BAND=k + 1):
+            assert np.array_equal(host(ops.gaussian_blur(d, k, sigma, direct=True)), want), (w, h, "short bands")
+    frames = np.stack([S.synth_image(300 + f, 516, 50) for f in range(3)])
+    got = host(ops.gaussian_blur(to_dev(frames, dev), k, sigma, direct=True))
+    for f in range(3):
+        assert np.array_equal(got[f], golden.gaussian(frames[f], k, sigma, threads=8))
+
+
 # ------------------------------------------------------------------ batches, strips, chain
 def test_batch_equals_per_frame(dev, golden):
     w, h, b = 130, 37, 5

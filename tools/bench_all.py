@@ -72,7 +72,7 @@ report(f"median 5x5 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 5,
 for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)):
     report(f"Gaussian {k}x{k} sigma {s}, separable ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out), 20)
 for k, s in ((3, 7.0), (5, 1.0), (7, 1.5)):
-    report(f"Gaussian {k}x{k}, direct = the reference's summation order, bit-exact ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out, direct=True), 10, "VALU-bound: k*k fma per pixel and channel")
+    report(f"Gaussian {k}x{k}, direct = the reference's summation order, bit-exact ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out, direct=True), 10, "VALU-bound: k*k fma per pixel and channel; 5x5 and 7x7: csrc/gauss_direct.hip")
 report(f"Gaussian 9x9, direct, LDS tiles ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 9, 2.0, out, direct=True), 10, "VALU-bound: 243 fma per pixel")
 report(f"fused chain gray>gauss5>median3>Sobel ({C})", "C2 chain", px, 8, lambda: ops.fused_chain(fr, 1.0, out), None, "the four kernels move 32 B/px")
 bufs = [torch.empty_like(fr) for _ in range(3)] + [out]
@@ -123,6 +123,20 @@ C5 = "16 x 4096x4096"
 report(f"fft2d forward ({C5})", "cufftExecC2C :690-701", pxf, 32, lambda: ops.fft2d(x, out=f), 10)
 report(f"fft2d inverse ({C5})", "cufftExecC2C :741-751", pxf, 32, lambda: ops.fft2d(f, inverse=True, out=y), 10)
 report(f"fft2d forward + inverse ({C5})", "C5 round trip", pxf, 64, lambda: (ops.fft2d(x, out=f), ops.fft2d(f, inverse=True, out=y)), 10)
+# the other sizes of the two-pass plan (same 2 GiB of planes), and the device tier of imageFFTImageGenerate /
+# compressImage with the conversions fused into the passes (8 images per launch)
+for (r, c, b) in ((2048, 2048, 64), (1024, 1024, 256), (1024, 4096, 64), (4096, 1024, 64)):
+    xs, fs_, ys = x.view(b, r, c), f.view(b, r, c), y.view(b, r, c)
+    report(f"fft2d forward + inverse ({b} x {c}x{r})", "cufftExecC2C", pxf, 64, lambda: (ops.fft2d(xs, out=fs_), ops.fft2d(fs_, inverse=True, out=ys)), 10)
+for nn, bb in ((4096, 8), (2048, 32)):
+    imgs = ops.synth(5, nn, nn * bb).reshape(bb, nn, nn, 4)
+    wsh = torch.empty(ops.fft_highpass_workspace_bytes(nn, nn, bb), dtype=torch.uint8, device="cuda")
+    outs = torch.empty_like(imgs)
+    report(f"imageFFTImageGenerate, device tier, fused passes ({bb} x {nn}x{nn})", ":633-791", bb * nn * nn, 160, lambda: ops.fft_highpass(imgs, 10.0, outs, wsh), 10,
+           "B/px: 4 + 3 x 8 written, 3 x 16 per cols pass x 2, 3 x 8 + 4 at the end")
+    with ops.tuning(MI_FFT_FUSED_SPECTRAL=0):
+        report(f"the same, step by step ({bb} x {nn}x{nn})", ":633-791", bb * nn * nn, 160, lambda: ops.fft_highpass(imgs, 10.0, outs, wsh), 10, "same algorithmic bytes, nine passes")
+    del imgs, wsh, outs
 one = x[0]
 report("fftShift (4096x4096)", ":564-583", n * n, 16, lambda: ops.fftshift_(one), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")
 report("highpassFilter (4096x4096)", ":530-549", n * n, 16, lambda: ops.highpass_(one, 10.0), 20, "Infinity-Cache resident (working set < 256 MiB): NOT an HBM number")

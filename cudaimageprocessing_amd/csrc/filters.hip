@@ -1042,9 +1042,6 @@ __global__ __launch_bounds__(256) void gauss_direct_march_kernel(const u32* __re
 #ifndef MI_CHAIN_BURST
 #define MI_CHAIN_BURST 3  // rows per request burst (ring of 2 * BURST rows per wave in LDS); 0: one row per step, in registers
 #endif
-#ifndef MI_CHAIN_VW
-#define MI_CHAIN_VW 0     // 1: Gaussian and grayscale weights in vector registers
-#endif
 #ifndef MI_CHAIN_WAVES
 #define MI_CHAIN_WAVES 1  // waves per SIMD the register allocation must allow (1: whatever the code needs)
 #endif
@@ -1080,17 +1077,6 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
         else return from_right(v);
     };
 
-    // The weights as pairs in vector registers (MI_CHAIN_VW): an instruction that reads a scalar register issues
-    // more slowly here than the same instruction on vector registers (tools/opbench.hip, profiles/r03_opbench.txt)
-    f32x2 cw[5], cg[3] = {splat2(0.587f), splat2(0.299f), splat2(0.114f)};
-#pragma unroll
-    for (int t = 0; t < 5; t++) cw[t] = splat2(gw.w[t]);
-    if constexpr (MI_CHAIN_VW != 0) {
-#pragma unroll
-        for (int t = 0; t < 5; t++) asm volatile("" : "+v"(cw[t]));
-#pragma unroll
-        for (int t = 0; t < 3; t++) asm volatile("" : "+v"(cg[t]));
-    }
     // stage 1+2a: grayscale of 4 pixels (as floats holding integers), then the Gaussian row pass
     // (two pixels per packed fp32 operation; each lane of a packed operation is the scalar one)
     auto gray_hrow = [&](u32x4 p, f32x2 (&h)[2]) {
@@ -1102,9 +1088,9 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
             const f32x2 r = {(float)(a & 0xffu), (float)(b & 0xffu)};
             const f32x2 gg = {(float)((a >> 8) & 0xffu), (float)((b >> 8) & 0xffu)};
             const f32x2 bl = {(float)((a >> 16) & 0xffu), (float)((b >> 16) & 0xffu)};
-            const f32x2 t = cg[0] * gg;
-            const f32x2 u = __builtin_elementwise_fma(cg[1], r, t);
-            f32x2 v = __builtin_elementwise_fma(cg[2], bl, u);
+            const f32x2 t = 0.587f * gg;
+            const f32x2 u = __builtin_elementwise_fma((f32x2)(0.299f), r, t);
+            f32x2 v = __builtin_elementwise_fma((f32x2)(0.114f), bl, u);
             if constexpr (MI_CHAIN_DBG == 4) v = r;
             f[2 + 2 * q] = __builtin_floorf(v.x);        // == (float)(uchar)v, v >= 0
             f[3 + 2 * q] = __builtin_floorf(v.y);
@@ -1115,10 +1101,10 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
         f[7] = __builtin_bit_cast(float, xr(__builtin_bit_cast(u32, f[3]), std::integral_constant<int, 1>{}));
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            f32x2 sum = cw[0] * f32x2{f[2 * q], f[2 * q + 1]};
+            f32x2 sum = gw.w[0] * f32x2{f[2 * q], f[2 * q + 1]};
 #pragma unroll
             for (int t = 1; t < 5; t++)
-                sum = __builtin_elementwise_fma(cw[t], f32x2{f[2 * q + t], f[2 * q + 1 + t]}, sum);
+                sum = __builtin_elementwise_fma((f32x2)(gw.w[t]), f32x2{f[2 * q + t], f[2 * q + 1 + t]}, sum);
             if constexpr (MI_CHAIN_DBG == 5) sum = f32x2{f[2 * q + 2], f[2 * q + 3]};
             h[q] = sum;
         }
@@ -1164,9 +1150,9 @@ __global__ __launch_bounds__(256, MI_CHAIN_WAVES) void chain_kernel(const u32* _
             float fb[4];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                f32x2 a = cw[2] * win[(s + 2) % 5][q];
-                a = __builtin_elementwise_fma(cw[0], win[s % 5][q] + win[(s + 4) % 5][q], a);
-                a = __builtin_elementwise_fma(cw[1], win[(s + 1) % 5][q] + win[(s + 3) % 5][q], a);
+                f32x2 a = gw.w[2] * win[(s + 2) % 5][q];
+                a = __builtin_elementwise_fma((f32x2)(gw.w[0]), win[s % 5][q] + win[(s + 4) % 5][q], a);
+                a = __builtin_elementwise_fma((f32x2)(gw.w[1]), win[(s + 1) % 5][q] + win[(s + 3) % 5][q], a);
                 if constexpr (MI_CHAIN_DBG == 5) a = win[(s + 2) % 5][q];
                 fb[2 * q] = __builtin_truncf(a.x);
                 fb[2 * q + 1] = __builtin_truncf(a.y);

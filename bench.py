@@ -374,7 +374,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # under torch.distributed.run the process group is made for one rank too, so that the RCCL set-up, the barrier
+    # and the MAX all-reduce around the timed region are the code a one-GPU box can already run
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

@@ -256,7 +256,7 @@ def leg_c4(torch, ops, timer, rank, world, dev, steps):
     of shard.StripPlan: neighbour halo exchange (RCCL send/recv), interior rows meanwhile, edge bands."""
     from cudaimageprocessing_amd import _lib, shard
     w = h = 32768
-    filters = {"gaussian15": (_lib.FILTER_GAUSSIAN, 15, 2.5, "gauss_wide_kernel<7>"),
+    filters = {"gaussian15": (_lib.FILTER_GAUSSIAN, 15, 2.5, "gauss_mfma_kernel"),
                "median5": (_lib.FILTER_MEDIAN, 5, 0.0, "median5_kernel")}
     pad = max(shard._halo_rows(f, k) for f, k, _, _ in filters.values())
     plan = shard.StripPlan(w, h, rank, world, pad, dev)

@@ -7,7 +7,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libmi_imagetools.so")
 
-SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "gauss_direct.hip", "noalloc.hip", "strips.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
+SOURCES = ["api.hip", "host.hip", "filters.hip", "spectral.hip", "fft.hip", "gauss_direct.hip", "gauss_mfma.hip", "noalloc.hip", "strips.hip", "selftest.cpp", "shim.cpp", "stb_write.cpp"]
 HEADERS = ["common.h", "internal.h", "median5_network.h", "fft_twopass.h",
            os.path.join("..", "..", "include", "mi_imagetools.h"),
            os.path.join("..", "..", "include", "imageTools.h")]
@@ -72,18 +72,23 @@ GUARD_LIB_PATH = os.path.join(_PKG, "libmi_imagetools_guard.so")
 
 
 def build_guard(force=False):
-    """libmi_imagetools_guard.so: the same library with filters.hip compiled -DMI_ROWFEED_FULL_WAIT=1 (every
-    hand-counted s_waitcnt in RowFeed replaced by vmcnt(0), common.h).  Test infrastructure: tests/test_gpu_guard.py
-    holds the product library to it bit for bit.  Only filters.hip uses RowFeed; the other objects are shared."""
+    """libmi_imagetools_guard.so: the same library with filters.hip and gauss_mfma.hip compiled
+    -DMI_ROWFEED_FULL_WAIT=1 (every hand-counted s_waitcnt -- RowFeed in common.h, the block feed of
+    gauss_mfma_kernel -- replaced by vmcnt(0)).  Test infrastructure: tests/test_gpu_guard.py holds the product
+    library to it bit for bit.  The other objects are shared."""
     lib = build()
-    src = os.path.join(_CSRC, "filters.hip")
-    deps = [src, os.path.join(_CSRC, "common.h"), os.path.join(_CSRC, "internal.h"), os.path.join(_CSRC, "median5_network.h"), lib]
+    guarded = ["filters.hip", "gauss_mfma.hip"]
+    deps = [os.path.join(_CSRC, f) for f in guarded + ["common.h", "internal.h", "median5_network.h"]] + [lib]
     if not force and os.path.exists(GUARD_LIB_PATH) and all(os.path.getmtime(GUARD_LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return GUARD_LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    obj = os.path.join(_CSRC, "filters_guard.o")
-    subprocess.check_call([hipcc] + FLAGS + ["-DMI_ROWFEED_FULL_WAIT=1", "-c", src, "-o", obj])
-    objs = [obj if s == "filters.hip" else os.path.join(_CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES]
+    procs = []
+    for f in guarded:
+        obj = os.path.join(_CSRC, os.path.splitext(f)[0] + "_guard.o")
+        procs.append(subprocess.Popen([hipcc] + FLAGS + FILE_FLAGS.get(f, []) + ["-DMI_ROWFEED_FULL_WAIT=1", "-c", os.path.join(_CSRC, f), "-o", obj]))
+    if any(p.wait() != 0 for p in procs):
+        raise RuntimeError("hipcc failed (guard build)")
+    objs = [os.path.join(_CSRC, os.path.splitext(s)[0] + ("_guard.o" if s in guarded else ".o")) for s in SOURCES]
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", GUARD_LIB_PATH] + objs + ["-lz", "-pthread"])
     return GUARD_LIB_PATH
 

@@ -1773,6 +1773,9 @@ static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
     return true;
 }
 
+// gauss_mfma.hip: separable Gaussians 7x7..15x15 on the matrix cores (aligned images); 1 = not applicable
+int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g);
+
 // gauss_direct.hip: the 5x5 and 7x7 direct Gaussians (weights: the k*k table, row-major)
 int launch_gauss_direct_win(int k, int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const float* weights);
 
@@ -2120,6 +2123,10 @@ int launch_filter(const FilterArgs& a)
         break;
     }
     case MI_FILTER_GAUSSIAN: {
+        if (aligned && a.ksize >= 7 && a.ksize <= 15 && tuning().gauss_mfma && tuning().gauss_wide) {
+            const int rc = launch_gauss_mfma(a.ksize, a.sigma, a.stream, in, out, g);
+            if (rc != 1) return rc;
+        }
         GaussW gw;
         gaussian_kernel_1d(a.ksize, a.sigma, gw.w);
         switch (a.ksize / 2) {

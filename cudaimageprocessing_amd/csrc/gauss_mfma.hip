@@ -1,0 +1,366 @@
+// gauss_mfma.hip -- separable Gaussian blur 7x7 .. 17x17 with both passes on the matrix cores (gfx950).
+//
+// Reference: imageGaussianBlur, /root/reference/kernels/imageTools.cu:287-311 (direct k x k fp32 sum, truncating
+// store).  The separable form is allowed +-1 level; gauss_wide_kernel (filters.hip) meets it in
+// 16-bit fixed point on the vector ALUs and is bound by them (75 vector instructions per pixel at 15x15, two waves
+// per SIMD: 0.44 of the HBM roofline).  A 1-D filter over 16 outputs is a banded (Toeplitz) 32 x 16 matrix applied
+// to a window of 32 inputs, so each pass of a 16 x 16-pixel tile is v_mfma_f32_16x16x32_f16 instructions:
+//
+//   row pass     D[row][x]  = sum_k  A[row][k] * T[k][x]      A = 16 image rows x (16 pixels x 2 channels) as f16
+//   column pass  D2[x][y]   = sum_k  A2[x][k]  * T2[k][y]     A2 = the row pass's result for 32 rows, as f16
+//
+// What makes this cheap is that the contraction index k may be permuted freely (the same way in both operands):
+//   * a lane's four RGBA pixels become A-operand registers with ONE v_perm_b32 per pixel and channel pair:
+//     (R | 0x6400, G | 0x6400) is the f16 pair (1024 + R, 1024 + G), so k runs over (pixel, channel) and the
+//     Toeplitz operand has zeros in the other channel's slots; the 1024 * sum(w) this adds is the accumulator's
+//     start value;
+//   * the row pass's result (lane: pixel x = lane % 16, rows 4 * (lane / 16) .. + 3) IS the column pass's operand
+//     layout once k is read as (row block, lane / 16, row % 4): two v_cvt_pk_f16_f32 and no cross-lane traffic;
+//   * with the column pass transposed (pixels as M, output rows as N) a lane ends up with four adjacent pixels of one
+//     output row: a 16-byte chunk.
+// About 30 vector instructions and 9 MFMAs per 256 pixels where the fixed-point kernel spends 300.
+//
+// Execution: one wave per workgroup owns a strip of 128 pixels (8 tiles) and walks down 16-row blocks aligned to
+// ABSOLUTE image rows (so the arithmetic of an output pixel does not depend on how a launch is cut into bands or
+// strips: any decomposition gives the same bytes).  A block's rows arrive by LDS-DMA (buffer_load ... lds, 16 bytes
+// per lane) in two buffers used in turn; the 16-byte chunk c of row r lands in slot (c + r) % 32 of the row (the DMA's
+// lanes fetch their chunks in that order), which makes both the operand reads (16 rows, one chunk) and the result
+// writes conflict-free.  Results go back into the buffer they came from -- tile t's 16 x 16 pixels replace input
+// chunks that tiles > t no longer need -- and leave as dense 512-byte row segments.
+//
+// Arithmetic: weights rounded to f16 with the centre weight rounded UP so that sum(w) >= 1 (a constant image
+// stays constant), row-pass results kept as f16 of (value - 128) (spacing <= 1/16), fp32 accumulation, a bias
+// of 1/16 before the truncating store.  Error before truncation: 255 * 2^-12 per pass from the weights + 1/32
+// from the f16 rows + the bias: |e| < 0.3, inside the +-1 level the separable form is allowed.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "internal.h"
+
+namespace mi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+struct GaussMfma {
+    float w[17];     // weights w[0 .. 2R], zero beyond, as two f16 values each: w = w[t] + wl[t] to 2^-22 of its size
+    float wl[17];
+    float c1;        // row-pass accumulator start: -(1024 * sum(w) + 128)
+    float c2;        // column-pass accumulator start: 128 * sum(w) + bias - 0.5 (v_cvt_pk_u8_f32 rounds to nearest)
+    int R;
+    int ob_first;    // first output block of the launch: output block b holds rows 16 b + 8 .. 16 b + 23
+    int nob;         // output blocks of the launch
+    int bpb;         // output blocks per band
+};
+
+#ifndef MI_GM_WAVES
+#define MI_GM_WAVES 2
+#endif
+#ifndef MI_GM_BIAS
+#define MI_GM_BIAS (1.0 / 256.0)   // added before the truncating store: covers fp32 accumulation error, so that a constant image stays constant
+#endif
+
+constexpr int GM_MAIN = 16 * 512;          // 16 rows x 128 pixels
+#define GM_BUF (GM_MAIN + 1024)            // + 16 rows x (8 pixels left, 8 pixels right)
+
+template <int N>
+static MI_DEV void gm_wait_vm()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MI_ROWFEED_FULL_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+static MI_DEV void gm_wait_lds()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
+__global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
+                                                                      const Geo g, const GaussMfma gm)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    const int lane = j.lane, r16 = lane & 15, grp = lane >> 4;
+    const int R = gm.R, W = g.W, pitch = W * 4;
+    const int cx0 = j.strip * 128;
+    const int ntile = min(8, (W - cx0 + 15) >> 4);
+    // this band's output blocks [ob0, ob0 + n) and output rows [ya, yb)
+    const int ob0 = gm.ob_first + j.band * gm.bpb;
+    const int n = min(gm.bpb, gm.ob_first + gm.nob - ob0);
+    const int ya = max(g.y_begin, 16 * ob0 + 8), yb = min(g.y_end, 16 * (ob0 + n) + 8);
+
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * GM_BUF];
+
+    // ---- Toeplitz operands, built once per wave from a zero-padded weight table in LDS: tbl[24 + t] = w[t]
+    {
+        float wv = 0.f, wlv = 0.f;
+#pragma unroll
+        for (int t = 0; t < 17; t++) { wv = (lane == 24 + t) ? gm.w[t] : wv; wlv = (lane == 24 + t) ? gm.wl[t] : wlv; }
+        reinterpret_cast<float*>(ring)[lane] = wv;
+        reinterpret_cast<float*>(ring)[64 + lane] = wlv;
+    }
+    const float* tbl = reinterpret_cast<const float*>(ring);
+    // [0]: the weights' leading f16, [1]: their remainder
+    h8 bR[2][2], bG[2][2], b2[2];
+#pragma unroll
+    for (int part = 0; part < 2; part++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                // k slot (pixel p of this lane group's chunk, channel): input pixel 16 h + 4 grp + p - 8 of the window,
+                // output pixel r16: tap index (16 h + 4 grp + p - 8) - r16 + R
+                const float v = tbl[64 * part + 24 + 16 * h + 4 * grp + p - 8 - r16 + R];
+                bR[part][h][2 * p] = (_Float16)v; bR[part][h][2 * p + 1] = (_Float16)0.f;
+                bG[part][h][2 * p] = (_Float16)0.f; bG[part][h][2 * p + 1] = (_Float16)v;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // k slot i: row 4 grp + i of the upper block (i < 4), row 4 grp + i - 4 of the lower one; output row 8 + r16
+            const int rel = i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4);
+            b2[part][i] = (_Float16)tbl[64 * part + 24 + rel - 8 - r16 + R];
+        }
+    }
+    gm_wait_lds();       // the table has been read: the ring is free for the first rows
+
+    // ---- addressing
+    const u32* in = in_ + (i64)j.frame * g.in_frame_stride;
+    u32* out = out_ + (i64)j.frame * g.out_frame_stride;
+    const i64 fmin = (i64)(16 * ob0) * W + cx0 - 8;              // lowest flat pixel index this wave can ask for
+    const i64 base = fmin > g.in_lo ? fmin : g.in_lo;
+    i64 bytes = (g.in_hi - base) * 4;
+    bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFF00LL ? 0x7FFFFF00LL : bytes);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
+    const int delta0 = (int)((fmin + 8 - base) * 4);             // byte offset of (row 16 ob0, pixel cx0)
+    // main rows: DMA instruction i brings rows 2i, 2i + 1 of the block; lane -> (row 2i + hi, slot), chunk (slot - row) % 32
+    const int hi = lane >> 5, slot = lane & 31;
+    const int c0 = (slot - hi) & 31;
+    const int main_lane = delta0 + hi * pitch;
+    // halo: lane -> (group q = lane / 16, row r16); groups 0, 1 = chunks -2, -1; groups 2, 3 = chunks 32, 33
+    const int halo_lane = delta0 + r16 * pitch + (grp < 2 ? grp - 2 : 30 + grp) * 16;
+    auto request = [&](int s, int b) __attribute__((always_inline)) {     // block s of the band -> buffer b
+        unsigned char* dst = ring + b * GM_BUF;
+        const int rowoff = 16 * s * pitch;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + 1024 * i), 16,
+                                                     main_lane + rowoff + 2 * i * pitch + (((c0 - 2 * i) & 31) << 4), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + GM_MAIN), 16,
+                                                 halo_lane + rowoff, 0, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((i64)ya * W - g.out_origin)), 0,
+                                                                        max(yb - ya, 0) * pitch, 0x00020000);
+    const int st_px = cx0 + 4 * slot;                              // first pixel of the chunk this lane stores
+    const int st_lane = st_px < W ? hi * pitch + st_px * 4 : (int)0x80000000;
+    const bool st_first = st_px == 0, st_last = st_px + 4 == W;
+
+    // LDS byte offsets (within a buffer) of this lane's operand chunks: half j = pixels 16 j - 8 .. 16 j + 7, chunk 4 j - 2 + grp
+    const int kap = (grp - 2 + r16) & 31;
+    const int halo_at = GM_MAIN + ((16 * grp + r16) << 4);
+    const int rd_row = r16 * 512;
+    const int wr_kap = (grp + r16) & 31;
+
+    const f32x4 c1v = {gm.c1, gm.c1, gm.c1, gm.c1}, c2v = {gm.c2, gm.c2, gm.c2, gm.c2};
+    u32 win[8][3][2];          // the row pass of the upper block, per tile and channel: rows 4 grp .. + 3 as two f16 pairs
+
+    request(0, 0);
+    request(1, 1);
+    for (int s = 0; s <= n; s++) {
+        const int b = s & 1;
+        if (s + 1 <= n) { if (s <= 1) gm_wait_vm<9>(); else gm_wait_vm<17>(); }
+        else gm_wait_vm<0>();
+        unsigned char* buf = ring + b * GM_BUF;
+        const bool prime = s == 0;
+
+        u32x4 raw[9];
+#pragma unroll
+        for (int h = 0; h < 9; h++) {
+            int at = rd_row + (((kap + 4 * h) & 31) << 4);
+            if (h == 0) at = grp < 2 ? halo_at : at;
+            if (h == 8) at = grp < 2 ? at : halo_at;
+            raw[h] = *reinterpret_cast<const u32x4*>(buf + at);
+        }
+        u32x4 aRG, aBA;
+        auto widen = [&](const u32x4& q, u32x4& rg, u32x4& ba) __attribute__((always_inline)) {
+            rg.x = __builtin_amdgcn_perm(0x64646464u, q.x, 0x04010400u); ba.x = __builtin_amdgcn_perm(0x64646464u, q.x, 0x04030402u);
+            rg.y = __builtin_amdgcn_perm(0x64646464u, q.y, 0x04010400u); ba.y = __builtin_amdgcn_perm(0x64646464u, q.y, 0x04030402u);
+            rg.z = __builtin_amdgcn_perm(0x64646464u, q.z, 0x04010400u); ba.z = __builtin_amdgcn_perm(0x64646464u, q.z, 0x04030402u);
+            rg.w = __builtin_amdgcn_perm(0x64646464u, q.w, 0x04010400u); ba.w = __builtin_amdgcn_perm(0x64646464u, q.w, 0x04030402u);
+        };
+        widen(raw[0], aRG, aBA);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (t < ntile) {
+                u32x4 nRG, nBA;
+                widen(raw[t + 1], nRG, nBA);
+                const h8 a0 = __builtin_bit_cast(h8, aRG), a1 = __builtin_bit_cast(h8, nRG);
+                const h8 d0 = __builtin_bit_cast(h8, aBA), d1 = __builtin_bit_cast(h8, nBA);
+                f32x4 mid[3];
+                // (the small terms first: they are added to the start value at full precision)
+                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[1][0], c1v, 0, 0, 0);
+                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[1][0], c1v, 0, 0, 0);
+                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[1][0], c1v, 0, 0, 0);
+                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[1][1], mid[0], 0, 0, 0);
+                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[1][1], mid[1], 0, 0, 0);
+                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[1][1], mid[2], 0, 0, 0);
+                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], mid[0], 0, 0, 0);
+                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], mid[1], 0, 0, 0);
+                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], mid[2], 0, 0, 0);
+                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[0][1], mid[0], 0, 0, 0);
+                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[0][1], mid[1], 0, 0, 0);
+                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[0][1], mid[2], 0, 0, 0);
+                aRG = nRG; aBA = nBA;
+                u32 lo[3], hi2[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    lo[c] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].x, mid[c].y}, h2));
+                    hi2[c] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].z, mid[c].w}, h2));
+                }
+                if (!prime) {
+                    f32x4 o3[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const u32x4 a2 = {win[t][c][0], win[t][c][1], lo[c], hi2[c]};
+                        o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[1], c2v, 0, 0, 0);
+                        o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[0], o3[c], 0, 0, 0);
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        u32 v = 0xFF000000u;
+                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[0][i], 0, v);
+                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[1][i], 1, v);
+                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[2][i], 2, v);
+                        o[i] = v;
+                    }
+                    // output row r16 of the block, pixels 16 t + 4 grp .. + 3: chunk 4 t + grp, slot (chunk + row) % 32
+                    *reinterpret_cast<u32x4*>(buf + rd_row + (((wr_kap + 4 * t) & 31) << 4)) = o;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) { win[t][c][0] = lo[c]; win[t][c][1] = hi2[c]; }
+            }
+        }
+        if (!prime) {
+            // the block's 16 output rows, 16 ob + 8 + r for output block ob = ob0 + s - 1, as dense row segments
+            const int y0 = 16 * (ob0 + s - 1) + 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int r = 2 * i + hi;
+                u32x4 v = *reinterpret_cast<const u32x4*>(buf + r * 512 + (((slot + r) & 31) << 4));
+                const int y = y0 + r;
+                const bool rowok = y >= 1 && y <= g.H - 2;
+                v.x = (rowok && !st_first) ? v.x : 0u;
+                v.y = rowok ? v.y : 0u;
+                v.z = rowok ? v.z : 0u;
+                v.w = (rowok && !st_last) ? v.w : 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + 2 * i - ya) * pitch, 0, 2);
+            }
+        }
+        gm_wait_lds();      // every read of this buffer has returned before the DMA may overwrite it
+        if (s + 2 <= n) request(s + 2, b);
+    }
+#endif
+}
+
+// fp32 -> f16 bit pattern, round to nearest even (host side; positive finite values below 65504)
+static unsigned short f16_bits(float f)
+{
+    u32 x;
+    __builtin_memcpy(&x, &f, 4);
+    const int e = (int)((x >> 23) & 0xff) - 127 + 15;
+    u32 m = x & 0x7fffffu;
+    if (e >= 31) return 0x7bff;
+    if (e <= 0) {                         // subnormal half
+        if (e < -10) return 0;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        u32 hm = m >> shift;
+        const u32 rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1))) hm++;
+        return (unsigned short)hm;
+    }
+    u32 h = ((u32)e << 10) | (m >> 13);
+    const u32 rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (unsigned short)h;
+}
+static float f16_value(unsigned short h)
+{
+    const int e = (h >> 10) & 31;
+    const u32 m = h & 0x3ffu;
+    if (e == 0) return (float)m * (1.0f / 16777216.0f);          // m * 2^-24
+    u32 x = ((u32)(e - 15 + 127) << 23) | (m << 13);
+    float f;
+    __builtin_memcpy(&f, &x, 4);
+    return f;
+}
+
+// f16 weights for gauss_mfma_kernel; false when the kernel does not apply
+static bool gauss_mfma_weights(int k, float sigma, GaussMfma* gm)
+{
+    const int R = k / 2;
+    if (R < 1 || R > 8) return false;
+    float w[MI_MAX_KERNEL_SIZE];
+    gaussian_kernel_1d(k, sigma, w);
+    double others = 0.0;
+    for (int t = 0; t < 17; t++) gm->w[t] = gm->wl[t] = 0.f;
+    for (int t = 0; t < k; t++) {
+        if (t == R) continue;
+        gm->w[t] = f16_value(f16_bits(w[t]));
+        gm->wl[t] = f16_value(f16_bits(w[t] - gm->w[t]));
+        others += (double)gm->w[t] + (double)gm->wl[t];
+    }
+    // centre weight: its remainder is the smallest f16 that makes the sum at least 1
+    const double want = 1.0 - others;
+    if (!(want > 0.0)) return false;
+    gm->w[R] = f16_value(f16_bits((float)want));
+    const double rest = want - (double)gm->w[R];
+    unsigned short cb = f16_bits((float)fabs(rest));
+    float cl = f16_value(cb);
+    if (rest < 0.0) { if ((double)cl > -rest) cl = f16_value((unsigned short)(cb - 1)); cl = -cl; }
+    else if ((double)cl < rest) cl = f16_value((unsigned short)(cb + 1));
+    gm->wl[R] = cl;
+    const double S = others + (double)gm->w[R] + (double)cl;
+    gm->c1 = (float)-(1024.0 * S + 128.0);
+    gm->c2 = (float)(128.0 * S + MI_GM_BIAS - 0.5);
+    gm->R = R;
+    return true;
+}
+
+// 0: launched; 1: not applicable (the caller falls back to the vector-ALU kernels); < 0 or a HIP error otherwise
+int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g)
+{
+    GaussMfma gm;
+    if (!gauss_mfma_weights(k, sigma, &gm)) return 1;
+    const int W = g.W;
+    // output blocks that intersect [y_begin, y_end): block b holds rows 16 b + 8 .. 16 b + 23
+    const int ob_first = (g.y_begin + 8) / 16 - 1, ob_last = (g.y_end + 7) / 16 - 1;
+    gm.ob_first = ob_first;
+    gm.nob = ob_last - ob_first + 1;
+    if (gm.nob <= 0) return 0;
+    g.strips = (W + 127) / 128;
+    int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : 4;   // 64-row bands measured best (16 x 4K and 32768^2)
+    if (tuning().rows_per_band <= 0)
+        while (bpb > 1 && (i64)g.batch * g.strips * ((gm.nob + bpb - 1) / bpb) < 4096) bpb >>= 1;
+    // a band's rows are addressed through 32-bit buffer offsets
+    while (bpb > 1 && (i64)(bpb + 2) * 16 * W * 4 > (1LL << 30)) bpb >>= 1;
+    if ((i64)(bpb + 2) * 16 * W * 4 > (1LL << 30)) return 1;
+    gm.bpb = bpb;
+    g.rows_per_band = 16 * bpb;
+    g.bands = (gm.nob + bpb - 1) / bpb;
+    const i64 total = (i64)g.batch * g.bands * g.strips;
+    if (total > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
+    g.total_waves = (int)total;
+    g.xcd_remap = 1;
+    gauss_mfma_kernel<<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    return hip_status(hipGetLastError(), "MFMA Gaussian kernel launch");
+}
+
+}  // namespace mi

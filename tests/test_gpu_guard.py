@@ -1,6 +1,7 @@
 """A fence for the hand-counted waits.  RowFeed (csrc/common.h) replaces the compiler's waits for its
 LDS-DMA row bursts by `s_waitcnt vmcnt(K + L)` counted by hand; the count is right only while a row step
-issues exactly the vector-memory operations the comment there lists.  libmi_imagetools_guard.so is the same
+issues exactly the vector-memory operations the comment there lists (gauss_mfma_kernel counts the same way
+for its 16-row blocks).  libmi_imagetools_guard.so is the same
 library with every such wait replaced by vmcnt(0) (always safe).  Every kernel that uses RowFeed must give
 the same bytes in both builds on the bench's own 16 x 3840x2160 batch: a compiler upgrade that adds or
 drops a memory operation in a row loop shows up here as a difference, not as a rare wrong pixel."""
@@ -24,11 +25,22 @@ def guard():
     assert os.path.exists(GUARD_LIB_PATH), f"{GUARD_LIB_PATH} is missing: python -m cudaimageprocessing_amd.build"
     g = C.CDLL(GUARD_LIB_PATH)
     for name in ("mi_sobel_u8x4_dev", "mi_meanblur_u8x4_dev", "mi_medianblur_u8x4_dev", "mi_gaussian_u8x4_dev",
-                 "mi_chain_gray_gauss5_median3_sobel_u8x4_dev"):
+                 "mi_chain_gray_gauss5_median3_sobel_u8x4_dev", "mi_debug_set_tuning"):
         fn = getattr(g, name)
         fn.argtypes = _lib.SIGNATURES[name]
         fn.restype = C.c_int
     return g
+
+
+def _gauss_wide(k):
+    """the vector-ALU kernel (gauss_wide_kernel, a RowFeed user) instead of the matrix-core one, in either library"""
+    def call(L, i, o, w, h, b):
+        assert L.mi_debug_set_tuning(b"MI_GAUSS_MFMA", 0) == 0
+        try:
+            return L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.4 * k, 0, None)
+        finally:
+            L.mi_debug_set_tuning(b"MI_GAUSS_MFMA", 1)
+    return call
 
 
 # (label, how to call it through a library handle)
@@ -38,6 +50,7 @@ CASES = [("sobel", lambda L, i, o, w, h, b: L.mi_sobel_u8x4_dev(i, o, w, h, b, N
 CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, k, None))(k)) for k in (3, 5, 7, 9, 11, 13, 15)]
 CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.4 * k, 0, None))(k))
           for k in (3, 5, 7, 9, 11, 13, 15)]
+CASES += [(f"gausswide{k}", _gauss_wide(k)) for k in (7, 11, 15)]
 
 
 @pytest.mark.parametrize("label,call", CASES, ids=[c[0] for c in CASES])

@@ -59,6 +59,9 @@ struct GaussMfma {
 #ifndef MI_GM_WAVES
 #define MI_GM_WAVES 2
 #endif
+#ifndef MI_GM_DBG
+#define MI_GM_DBG 0       // experiment builds only (wrong output): 1 = no stores, 2 = no loads, 3 = neither
+#endif
 #ifndef MI_GM_BIAS
 #define MI_GM_BIAS (1.0 / 256.0)   // added before the truncating store: covers fp32 accumulation error, so that a constant image stays constant
 #endif
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     // halo: lane -> (group q = lane / 16, row r16); groups 0, 1 = chunks -2, -1; groups 2, 3 = chunks 32, 33
     const int halo_lane = delta0 + r16 * pitch + (grp < 2 ? grp - 2 : 30 + grp) * 16;
     auto request = [&](int s, int b) __attribute__((always_inline)) {     // block s of the band -> buffer b
+        if (MI_GM_DBG >= 2) return;
         unsigned char* dst = ring + b * GM_BUF;
         const int rowoff = 16 * s * pitch;
 #pragma unroll
@@ -174,7 +178,8 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     request(1, 1);
     for (int s = 0; s <= n; s++) {
         const int b = s & 1;
-        if (s + 1 <= n) { if (s <= 1) gm_wait_vm<9>(); else gm_wait_vm<17>(); }
+        if (MI_GM_DBG >= 2) {}
+        else if (s + 1 <= n) { if (s <= 1 || MI_GM_DBG == 1) gm_wait_vm<9>(); else gm_wait_vm<17>(); }
         else gm_wait_vm<0>();
         unsigned char* buf = ring + b * GM_BUF;
         const bool prime = s == 0;
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                 v.y = rowok ? v.y : 0u;
                 v.z = rowok ? v.z : 0u;
                 v.w = (rowok && !st_last) ? v.w : 0u;
-                __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + 2 * i - ya) * pitch, 0, 2);
+                if (MI_GM_DBG == 1 || MI_GM_DBG == 3) { if (v.x == 0x12345678u && v.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane, 0, 2); }
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + 2 * i - ya) * pitch, 0, 2);
             }
         }
         gm_wait_lds();      // every read of this buffer has returned before the DMA may overwrite it

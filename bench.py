@@ -356,6 +356,12 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="time the four single-filter kernels as the step")
     ap.add_argument("--legs", default="c3,c4,c5", help="extra configurations to run after the headline one ('' = none)")
     ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--event-every", type=int, default=int(os.environ.get("MI_BENCH_EVENT_EVERY", "0")),
+                    help="0 (default): ONE pair of HIP events around the K timed launches of the fused step, average = "
+                         "elapsed / K (launch gaps included); n > 0: a pair around every n-th step's launch (a pair costs "
+                         "2-4 us, which lengthens both the step and the bracketed launch: 0.2145 / 0.2092 ms per step / per "
+                         "launch with n = 1 against 0.2071 / 0.2070 with one pair).  The four-kernel step always brackets "
+                         "every kernel.")
     args = ap.parse_args()
 
     import torch
@@ -431,17 +437,28 @@ def main():
     spin_up(step)
     for _ in range(args.warmup):
         step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] for _ in range(args.steps)]
+    every = 1 if args.unfused else max(0, args.event_every)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(n_ev)] if every and k % every == 0 else None
+          for k in range(args.steps)]
+    region = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    launch_stream = torch.cuda.current_stream()
     timer.barrier()
     t0 = time.perf_counter()
+    region[0].record(launch_stream)
     for k in range(args.steps):
         step(ev[k])
+    region[1].record(launch_stream)
     timer.barrier()
     elapsed = timer.max_over_ranks(time.perf_counter() - t0)
 
     # per-kernel launch durations (ms) from the events recorded inside the timed region
-    per_kernel = [sum(ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)) / args.steps
-                  for i in range(n_ev - 1)]
+    timed_ev = [e for e in ev if e is not None]
+    if timed_ev:
+        per_kernel = [sum(e[i].elapsed_time(e[i + 1]) for e in timed_ev) / len(timed_ev) for i in range(n_ev - 1)]
+        launch_timing = f"HIP event pair around {'every' if every == 1 else 'every %d-th' % every} launch inside the timed region"
+    else:
+        per_kernel = [region[0].elapsed_time(region[1]) / args.steps]
+        launch_timing = f"one HIP event pair around the {args.steps} launches of the timed region, elapsed / {args.steps} (launch gaps included)"
 
     # the four-kernel chain, timed after the K steps (same buffers, same events, same spin-up: the
     # kernels differ from the timed ones, so their first launches would otherwise be cold)
@@ -524,7 +541,8 @@ def main():
             "config": {"workload": f"C2 chain gray->gauss5(sigma 1.0)->median3->sobel, {W}x{H} RGBA u8, "
                                    f"batch {B} frames per GPU, device-resident, {desc}",
                        "frames_per_gpu": B, "width": W, "height": H, "sharding": f"batch x{world}"},
-            "roofline": roofline(kname, alg_bytes, kms, traffic.get(kname), traffic_source=traffic_source),
+            "roofline": roofline(kname, alg_bytes, kms, traffic.get(kname), traffic_source=traffic_source,
+                                 launch_timing=launch_timing),
             "checksum": headline_checksum,
             "process_group": {"backend": (dist.get_backend() if dist is not None else None),
                               "world_size": (dist.get_world_size() if dist is not None else 1)},

@@ -1775,6 +1775,7 @@ static bool gauss_wide_weights(int k, float sigma, GaussWide* gw)
 
 // gauss_mfma.hip: separable Gaussians 7x7..15x15 on the matrix cores (aligned images); 1 = not applicable
 int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g);
+int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g);
 
 // gauss_direct.hip: the 5x5 and 7x7 direct Gaussians (weights: the k*k table, row-major)
 int launch_gauss_direct_win(int k, int pol, int grid, hipStream_t s, const u32* in, u32* out, const Geo& g, const float* weights);
@@ -2029,6 +2030,12 @@ int launch_filter(const FilterArgs& a)
             }
         }
         return hip_status(hipGetLastError(), "generic filter kernel launch");
+    }
+
+    // mean blur 15x15 and 17x17 on the matrix cores (exact; gauss_mfma.hip; MI_MEAN_MFMA lowers the threshold to 5)
+    if (a.filter == MI_FILTER_MEAN && aligned && tuning().mean_mfma > 0 && a.ksize >= tuning().mean_mfma && a.ksize >= 5 && a.ksize <= 17) {
+        const int rc = launch_mean_mfma(a.ksize, a.stream, in, out, g);
+        if (rc != 1) return rc;
     }
 
     // wave-march kernels

@@ -34,6 +34,7 @@
 // from the f16 rows + the bias: |e| < 0.3, inside the +-1 level the separable form is allowed.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 
 #include "common.h"
 #include "internal.h"
@@ -50,6 +51,7 @@ struct GaussMfma {
     float wl[17];
     float c1;        // row-pass accumulator start: -(1024 * sum(w) + 128)
     float c2;        // column-pass accumulator start: 128 * sum(w) + bias - 0.5 (v_cvt_pk_u8_f32 rounds to nearest)
+    float rcp, d;    // mean (MODE 1): output = nearest integer to sum * rcp + d == sum / k^2, checked for every sum on the host
     int R;
     int ob_first;    // first output block of the launch: output block b holds rows 16 b + 8 .. 16 b + 23
     int nob;         // output blocks of the launch
@@ -84,6 +86,13 @@ static MI_DEV void gm_wait_lds()
 #endif
 }
 
+// MODE 0: Gaussian.  MODE 1: mean blur (imageMeanBlur, imageTools.cu:313-340) of size 2R + 1 <= 17, EXACT: weights 1.0,
+// so the row pass leaves the integer row sums (<= 17 * 255) in fp32; they are kept as 16-bit integers and enter the
+// column pass as two exact f16 parts, sum >> 6 against weights 64.0 and sum & 63 against weights 1.0 (0x6400 | x is the
+// f16 1024 + x again); every partial sum is an integer below 2^24, hence exact whatever the order inside the MFMA; the
+// integer division by k^2 is one fused multiply-add and the rounding of v_cvt_pk_u8_f32, verified for every reachable
+// sum on the host.  table part 0 = 1.0 in the window, part 1 = 64.0.
+template <int MODE>
 __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
                                                                       const Geo g, const GaussMfma gm)
 {
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     const int wr_kap = (grp + r16) & 31;
 
     const f32x4 c1v = {gm.c1, gm.c1, gm.c1, gm.c1}, c2v = {gm.c2, gm.c2, gm.c2, gm.c2};
-    u32 win[8][3][2];          // the row pass of the upper block, per tile and channel: rows 4 grp .. + 3 as two f16 pairs
+    u32 win[8][3][2];          // the row pass of the upper block, per tile and channel: rows 4 grp .. + 3 (see `cur` below)
 
     request(0, 0);
     request(1, 1);
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
         unsigned char* buf = ring + b * GM_BUF;
         const bool prime = s == 0;
 
-        u32x4 raw[9];
+        u32x4 raw[9];          // this lane's chunk of half h = pixels 16 h - 8 .. 16 h + 7 of the block's 16 rows
 #pragma unroll
         for (int h = 0; h < 9; h++) {
             int at = rd_row + (((kap + 4 * h) & 31) << 4);
@@ -208,48 +217,74 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                 const h8 a0 = __builtin_bit_cast(h8, aRG), a1 = __builtin_bit_cast(h8, nRG);
                 const h8 d0 = __builtin_bit_cast(h8, aBA), d1 = __builtin_bit_cast(h8, nBA);
                 f32x4 mid[3];
-                // (the small terms first: they are added to the start value at full precision)
-                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[1][0], c1v, 0, 0, 0);
-                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[1][0], c1v, 0, 0, 0);
-                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[1][0], c1v, 0, 0, 0);
-                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[1][1], mid[0], 0, 0, 0);
-                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[1][1], mid[1], 0, 0, 0);
-                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[1][1], mid[2], 0, 0, 0);
-                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], mid[0], 0, 0, 0);
-                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], mid[1], 0, 0, 0);
-                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], mid[2], 0, 0, 0);
+                if (MODE == 0) {
+                    // (the small terms first: they are added to the start value at full precision)
+                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[1][0], c1v, 0, 0, 0);
+                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[1][0], c1v, 0, 0, 0);
+                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[1][0], c1v, 0, 0, 0);
+                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[1][1], mid[0], 0, 0, 0);
+                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[1][1], mid[1], 0, 0, 0);
+                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[1][1], mid[2], 0, 0, 0);
+                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], mid[0], 0, 0, 0);
+                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], mid[1], 0, 0, 0);
+                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], mid[2], 0, 0, 0);
+                } else {
+                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], c1v, 0, 0, 0);
+                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], c1v, 0, 0, 0);
+                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], c1v, 0, 0, 0);
+                }
                 mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[0][1], mid[0], 0, 0, 0);
                 mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[0][1], mid[1], 0, 0, 0);
                 mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[0][1], mid[2], 0, 0, 0);
                 aRG = nRG; aBA = nBA;
-                u32 lo[3], hi2[3];
+                // what the window keeps of this block's rows 4 grp .. + 3, two registers per channel: MODE 0 f16 pairs; MODE 1
+                // the integer row sums (below 2^13), two to a register
+                u32 cur[3][2];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    lo[c] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].x, mid[c].y}, h2));
-                    hi2[c] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].z, mid[c].w}, h2));
+                    if constexpr (MODE == 0) {
+                        cur[c][0] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].x, mid[c].y}, h2));
+                        cur[c][1] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].z, mid[c].w}, h2));
+                    } else {
+                        cur[c][0] = (u32)mid[c].x | ((u32)mid[c].y << 16);
+                        cur[c][1] = (u32)mid[c].z | ((u32)mid[c].w << 16);
+                    }
                 }
                 if (!prime) {
                     f32x4 o3[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const u32x4 a2 = {win[t][c][0], win[t][c][1], lo[c], hi2[c]};
-                        o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[1], c2v, 0, 0, 0);
-                        o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[0], o3[c], 0, 0, 0);
+                        const u32x4 a2 = {win[t][c][0], win[t][c][1], cur[c][0], cur[c][1]};
+                        if constexpr (MODE == 0) {
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[1], c2v, 0, 0, 0);
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[0], o3[c], 0, 0, 0);
+                        } else {     // the two exact parts of the sums, sum >> 6 and sum & 63, each as 0x6400 | x = 1024 + x in f16
+                            u32x4 ah, al;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                ah[i] = ((a2[i] >> 6) & 0x007f007fu) | 0x64006400u;
+                                al[i] = (a2[i] & 0x003f003fu) | 0x64006400u;
+                            }
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), b2[1], c2v, 0, 0, 0);
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), b2[0], o3[c], 0, 0, 0);
+                        }
                     }
                     u32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         u32 v = 0xFF000000u;
-                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[0][i], 0, v);
-                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[1][i], 1, v);
-                        v = __builtin_amdgcn_cvt_pk_u8_f32(o3[2][i], 2, v);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float f = MODE == 0 ? o3[c][i] : __builtin_fmaf(o3[c][i], gm.rcp, gm.d);
+                            v = __builtin_amdgcn_cvt_pk_u8_f32(f, c, v);
+                        }
                         o[i] = v;
                     }
                     // output row r16 of the block, pixels 16 t + 4 grp .. + 3: chunk 4 t + grp, slot (chunk + row) % 32
                     *reinterpret_cast<u32x4*>(buf + rd_row + (((wr_kap + 4 * t) & 31) << 4)) = o;
                 }
 #pragma unroll
-                for (int c = 0; c < 3; c++) { win[t][c][0] = lo[c]; win[t][c][1] = hi2[c]; }
+                for (int c = 0; c < 3; c++) { win[t][c][0] = cur[c][0]; win[t][c][1] = cur[c][1]; }
             }
         }
         if (!prime) {
@@ -336,15 +371,15 @@ static bool gauss_mfma_weights(int k, float sigma, GaussMfma* gm)
     const double S = others + (double)gm->w[R] + (double)cl;
     gm->c1 = (float)-(1024.0 * S + 128.0);
     gm->c2 = (float)(128.0 * S + MI_GM_BIAS - 0.5);
+    gm->rcp = 1.f; gm->d = 0.f;
     gm->R = R;
     return true;
 }
 
-// 0: launched; 1: not applicable (the caller falls back to the vector-ALU kernels); < 0 or a HIP error otherwise
-int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g)
+// Geometry shared by both modes.  0: launched; 1: not applicable; < 0 or a HIP error otherwise
+template <int MODE>
+static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Geo g)
 {
-    GaussMfma gm;
-    if (!gauss_mfma_weights(k, sigma, &gm)) return 1;
     const int W = g.W;
     // output blocks that intersect [y_begin, y_end): block b holds rows 16 b + 8 .. 16 b + 23
     const int ob_first = (g.y_begin + 8) / 16 - 1, ob_last = (g.y_end + 7) / 16 - 1;
@@ -365,8 +400,47 @@ int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out
     if (total > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
     g.total_waves = (int)total;
     g.xcd_remap = 1;
-    gauss_mfma_kernel<<<(int)total, 64, 0, s>>>(in, out, g, gm);
-    return hip_status(hipGetLastError(), "MFMA Gaussian kernel launch");
+    gauss_mfma_kernel<MODE><<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    return hip_status(hipGetLastError(), "matrix-core filter kernel launch");
+}
+
+int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g)
+{
+    GaussMfma gm;
+    if (!gauss_mfma_weights(k, sigma, &gm)) return 1;
+    return launch_mfma<0>(gm, s, in, out, g);
+}
+
+// Mean blur k x k, 5 <= k <= 17, exact.  rcp and d: nearest(sum * rcp + d) == sum / (k * k) for every sum a window of
+// bytes can reach, verified here once per size with the device's own operations (one fused multiply-add in fp32,
+// round to nearest even); 1 when no such pair is found (the caller falls back).
+int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
+{
+    const int R = k / 2;
+    if (k % 2 == 0 || R < 1 || R > 8) return 1;
+    static std::mutex mu;
+    static int state[18];            // 0 unknown, 1 verified, -1 failed
+    const float kk = (float)(k * k);
+    const float rcp = 1.0f / kk, d = 0.5f / kk - 0.5f;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (state[k] == 0) {
+            bool ok = true;
+            for (int sum = 0; sum <= 255 * k * k && ok; sum++) {
+                const float f = __builtin_fmaf((float)sum, rcp, d);
+                ok = (int)nearbyintf(f) == sum / (k * k);
+            }
+            state[k] = ok ? 1 : -1;
+        }
+        if (state[k] < 0) return 1;
+    }
+    GaussMfma gm;
+    for (int t = 0; t < 17; t++) { gm.w[t] = t < k ? 1.0f : 0.f; gm.wl[t] = t < k ? 64.0f : 0.f; }
+    gm.c1 = -1024.0f * (float)k;
+    gm.c2 = -1024.0f * 65.0f * (float)k;
+    gm.rcp = rcp; gm.d = d;
+    gm.R = R;
+    return launch_mfma<1>(gm, s, in, out, g);
 }
 
 }  // namespace mi

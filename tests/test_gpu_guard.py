@@ -32,6 +32,17 @@ def guard():
     return g
 
 
+def _mean_valu(k):
+    """the vector-ALU mean (mean_sep_kernel, a RowFeed user) instead of the matrix-core one, in either library"""
+    def call(L, i, o, w, h, b):
+        assert L.mi_debug_set_tuning(b"MI_MEAN_MFMA", 0) == 0
+        try:
+            return L.mi_meanblur_u8x4_dev(i, o, w, h, b, k, None)
+        finally:
+            L.mi_debug_set_tuning(b"MI_MEAN_MFMA", 15)
+    return call
+
+
 def _gauss_wide(k):
     """the vector-ALU kernel (gauss_wide_kernel, a RowFeed user) instead of the matrix-core one, in either library"""
     def call(L, i, o, w, h, b):
@@ -51,6 +62,7 @@ CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_de
 CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.4 * k, 0, None))(k))
           for k in (3, 5, 7, 9, 11, 13, 15)]
 CASES += [(f"gausswide{k}", _gauss_wide(k)) for k in (7, 11, 15)]
+CASES += [("mean17", lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 17, None)), ("meanvalu15", _mean_valu(15))]
 
 
 @pytest.mark.parametrize("label,call", CASES, ids=[c[0] for c in CASES])

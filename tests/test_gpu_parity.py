@@ -120,6 +120,41 @@ def test_mean_other_sizes(dev, golden, k):
     assert np.array_equal(host(ops.mean_blur(to_dev(white, dev), k)), golden.meanblur(white, k))
 
 
+@pytest.mark.parametrize("k", [5, 7, 9, 11, 13, 15, 17])
+def test_mean_on_the_matrix_cores_is_exact(dev, golden, k):
+    """gauss_mfma_kernel<1> (the default for 15x15 and 17x17; MI_MEAN_MFMA=5 sends every size it takes through it):
+    integer row sums on the matrix cores, two exact f16 parts into the column pass, the division as one fused
+    multiply-add -- bit-exact against the oracle on noise and on an all-white image (the largest sums), equal to the
+    vector-ALU kernels, and independent of band height and row strips."""
+    with ops.tuning(MI_MEAN_MFMA=5):
+        for (w, h) in ((516, 75), (128, 64), (64, 48), (260, 131), (8, 40), (20, 33)):
+            if k * k > w * h:
+                continue
+            for img in (S.synth_image(k + w, w, h), np.full((h, w, 4), 255, np.uint8)):
+                d = to_dev(img, dev)
+                got = ops.mean_blur(d, k)
+                assert np.array_equal(host(got), golden.meanblur(img, k)), (k, w, h)
+                with ops.tuning(MI_MEAN_MFMA=0):
+                    assert torch.equal(ops.mean_blur(d, k), got), (k, w, h)
+        w, h = 1000, 203
+        img = S.synth_image(3 * k, w, h)
+        d = to_dev(img, dev)
+        ref = ops.mean_blur(d, k)
+        assert np.array_equal(host(ref), golden.meanblur(img, k, threads=8))
+        for rpb in (1, 40, 512):
+            with ops.tuning(MI_ROWS_PER_BAND=rpb):
+                assert torch.equal(ops.mean_blur(d, k), ref), (k, rpb)
+        halo = ops.halo_rows(_lib.FILTER_MEAN, k)
+        edges = (0, 1, 9, 33, 100, 101, 203)
+        pieces = []
+        for y0, y1 in zip(edges[:-1], edges[1:]):
+            r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+            out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+            ops.filter_strip(_lib.FILTER_MEAN, d[r0:r1].contiguous(), out, w, h, r0, y0, y1, k, 0.0)
+            pieces.append(out)
+        assert torch.equal(torch.cat(pieces), ref), k
+
+
 # ------------------------------------------------------------------ median
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("kind", PATTERNS)

@@ -273,7 +273,7 @@ def leg_c4(torch, ops, timer, rank, world, dev, steps):
         def stage():
             plan.cur = 0                      # the input stays in buffer 0; a stage writes buffer 1
             plan.run_stage(fid, k, sigma)
-        elapsed, ms = timer.run(stage, steps, 1)
+        elapsed, ms = timer.run(stage, steps, 3)
         halo = shard._halo_rows(fid, k)
         # the same rows as ONE launch with the halos already in place (no exchange): the compute alone
         a = halo if rank > 0 else 0
@@ -282,7 +282,7 @@ def leg_c4(torch, ops, timer, rank, world, dev, steps):
 
         def compute_only():
             ops.filter_strip(fid, src[pad - a:pad + plan.n + b], dst[pad:pad + plan.n], w, h, plan.y0 - a, plan.y0, plan.y1, k, sigma)
-        _, ms_compute = timer.run(compute_only, steps, 1)
+        _, ms_compute = timer.run(compute_only, steps, 3)
 
         def exchange_only():
             sends, recvs = [], []
@@ -293,7 +293,7 @@ def leg_c4(torch, ops, timer, rank, world, dev, steps):
             shard._p2p(sends, recvs)()
         ms_halo = 0.0
         if world > 1:
-            _, ms_halo = timer.run(exchange_only, steps, 1)
+            _, ms_halo = timer.run(exchange_only, steps, 3)
         stage()
         res = plan.strip(1)                       # this rank's rows of the stage's output
         bands = sorted({0, (plan.n // 2) // 64 * 64, plan.n - 64})
@@ -323,7 +323,7 @@ def leg_c5(torch, ops, timer, rank, world, dev, steps):
     def roundtrip():
         ops.fft2d(x, out=f)
         ops.fft2d(f, inverse=True, out=y)
-    elapsed, ms = timer.run(roundtrip, steps, 2)
+    elapsed, ms = timer.run(roundtrip, steps, 3)
     px = batch * n * n
     # floating point: no byte checksum -- the round trip's error, Parseval and the DC coefficient instead
     err = max(float(torch.linalg.vector_norm((y[b] / (n * n) - x[b]).to(torch.complex128)) /
@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="time the four single-filter kernels as the step")
     ap.add_argument("--legs", default="c3,c4,c5", help="extra configurations to run after the headline one ('' = none)")
-    ap.add_argument("--leg-steps", type=int, default=10)
+    ap.add_argument("--leg-steps", type=int, default=30)
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("MI_BENCH_EVENT_EVERY", "0")),
                     help="0 (default): ONE pair of HIP events around the K timed launches of the fused step, average = "
                          "elapsed / K (launch gaps included); n > 0: a pair around every n-th step's launch (a pair costs "

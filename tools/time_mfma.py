@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ms per launch of the separable Gaussian 15x15 on 16 x 3840x2160 (A/B target for tools/_var libraries)."""
+"""ms per launch of the matrix-core Gaussian 15x15 and mean 17x17 on 16 x 3840x2160 (A/B target for tools/_var libraries)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,4 +18,5 @@ def timed(fn, n=200):
     return e0.elapsed_time(e1) / n
 for _ in range(400): ops.fused_chain(frames, 1.0, out)
 f = lambda: ops.gaussian_blur(frames, 15, 2.5, out)
-print(" ".join(f"{min(timed(f), timed(f)):.4f}" for _ in range(3)), flush=True)
+m = lambda: ops.mean_blur(frames, 17, out)
+print("gauss15 " + " ".join(f"{min(timed(f), timed(f)):.4f}" for _ in range(2)) + "   mean17 " + " ".join(f"{min(timed(m), timed(m)):.4f}" for _ in range(2)), flush=True)

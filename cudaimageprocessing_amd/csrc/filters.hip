@@ -2032,7 +2032,7 @@ int launch_filter(const FilterArgs& a)
         return hip_status(hipGetLastError(), "generic filter kernel launch");
     }
 
-    // mean blur 15x15 and 17x17 on the matrix cores (exact; gauss_mfma.hip; MI_MEAN_MFMA lowers the threshold to 5)
+    // mean blur 11x11 .. 17x17 on the matrix cores (exact; gauss_mfma.hip; MI_MEAN_MFMA moves the threshold)
     if (a.filter == MI_FILTER_MEAN && aligned && tuning().mean_mfma > 0 && a.ksize >= tuning().mean_mfma && a.ksize >= 5 && a.ksize <= 17) {
         const int rc = launch_mean_mfma(a.ksize, a.stream, in, out, g);
         if (rc != 1) return rc;

@@ -10,28 +10,29 @@
 //   column pass  D2[x][y]   = sum_k  A2[x][k]  * T2[k][y]     A2 = the row pass's result for 32 rows, as f16
 //
 // What makes this cheap is that the contraction index k may be permuted freely (the same way in both operands):
-//   * a lane's four RGBA pixels become A-operand registers with ONE v_perm_b32 per pixel and channel pair:
-//     (R | 0x6400, G | 0x6400) is the f16 pair (1024 + R, 1024 + G), so k runs over (pixel, channel) and the
-//     Toeplitz operand has zeros in the other channel's slots; the 1024 * sum(w) this adds is the accumulator's
-//     start value;
+//   * a lane's four RGBA pixels (one 16-byte chunk) become row-pass operand registers with ONE v_perm_b32 per channel
+//     and pixel pair: the bytes (b0, 0, b1, 0) are the f16 pair (b0 * 2^-24, b1 * 2^-24) -- f16 SUBNORMALS, which the
+//     MFMA takes at face value -- so the weight operand carries 2^15 and the column pass's the remaining 2^9; a tile's
+//     operand is the chunks of its two halves (pixels 16 t - 8 .. 16 t + 7 and the next 16), k slot = (half, pixel);
 //   * the row pass's result (lane: pixel x = lane % 16, rows 4 * (lane / 16) .. + 3) IS the column pass's operand
 //     layout once k is read as (row block, lane / 16, row % 4): two v_cvt_pk_f16_f32 and no cross-lane traffic;
 //   * with the column pass transposed (pixels as M, output rows as N) a lane ends up with four adjacent pixels of one
 //     output row: a 16-byte chunk.
-// About 30 vector instructions and 9 MFMAs per 256 pixels where the fixed-point kernel spends 300.
+// 12 MFMAs and about 45 vector instructions per 256 pixels where the fixed-point kernel spends 300 vector instructions.
+// (Round 3's first form interleaved two channels in one operand -- (1024 + R, 1024 + G) as 0x6400 | byte -- with zero
+// weights in the other channel's slots: 18 MFMAs per tile, 242 registers, 1.5 % slower; the mean 6.5 % slower.)
 //
 // Execution: one wave per workgroup owns a strip of 128 pixels (8 tiles) and walks down 16-row blocks aligned to
 // ABSOLUTE image rows (so the arithmetic of an output pixel does not depend on how a launch is cut into bands or
 // strips: any decomposition gives the same bytes).  A block's rows arrive by LDS-DMA (buffer_load ... lds, 16 bytes
 // per lane) in two buffers used in turn; the 16-byte chunk c of row r lands in slot (c + r) % 32 of the row (the DMA's
 // lanes fetch their chunks in that order), which makes both the operand reads (16 rows, one chunk) and the result
-// writes conflict-free.  Results go back into the buffer they came from -- tile t's 16 x 16 pixels replace input
-// chunks that tiles > t no longer need -- and leave as dense 512-byte row segments.
+// writes conflict-free.  Results go back into the buffer they came from and leave as dense 512-byte row segments.
 //
-// Arithmetic: weights rounded to f16 with the centre weight rounded UP so that sum(w) >= 1 (a constant image
-// stays constant), row-pass results kept as f16 of (value - 128) (spacing <= 1/16), fp32 accumulation, a bias
-// of 1/16 before the truncating store.  Error before truncation: 255 * 2^-12 per pass from the weights + 1/32
-// from the f16 rows + the bias: |e| < 0.3, inside the +-1 level the separable form is allowed.
+// Arithmetic (Gaussian): each weight as TWO f16 values (leading part and remainder; the centre's remainder rounded UP
+// so that sum(w) >= 1: a constant image stays constant), row-pass results kept as f16 of (value - 128) / 512 (spacing
+// <= 1/16 of a level), fp32 accumulation, 1/256 added before the truncating store.  Error before truncation < 0.05,
+// inside the +-1 level the separable form is allowed.
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -49,7 +50,7 @@ typedef float f32x2v __attribute__((ext_vector_type(2)));
 struct GaussMfma {
     float w[17];     // weights w[0 .. 2R], zero beyond, as two f16 values each: w = w[t] + wl[t] to 2^-22 of its size
     float wl[17];
-    float c1;        // row-pass accumulator start: -(1024 * sum(w) + 128)
+    float c1;        // row-pass accumulator start: -128 / 512 (mean: 2^14)
     float c2;        // column-pass accumulator start: 128 * sum(w) + bias - 0.5 (v_cvt_pk_u8_f32 rounds to nearest)
     float rcp, d;    // mean (MODE 1): output = nearest integer to sum * rcp + d == sum / k^2, checked for every sum on the host
     int R;
@@ -86,12 +87,13 @@ static MI_DEV void gm_wait_lds()
 #endif
 }
 
-// MODE 0: Gaussian.  MODE 1: mean blur (imageMeanBlur, imageTools.cu:313-340) of size 2R + 1 <= 17, EXACT: weights 1.0,
-// so the row pass leaves the integer row sums (<= 17 * 255) in fp32; they are kept as 16-bit integers and enter the
-// column pass as two exact f16 parts, sum >> 6 against weights 64.0 and sum & 63 against weights 1.0 (0x6400 | x is the
-// f16 1024 + x again); every partial sum is an integer below 2^24, hence exact whatever the order inside the MFMA; the
-// integer division by k^2 is one fused multiply-add and the rounding of v_cvt_pk_u8_f32, verified for every reachable
-// sum on the host.  table part 0 = 1.0 in the window, part 1 = 64.0.
+// MODE 0: Gaussian.  MODE 1: mean blur (imageMeanBlur, imageTools.cu:313-340) of size 2R + 1 <= 17, EXACT: weights 1.0
+// (times 2^15), and the row-pass accumulator starts at 2^14, whose last place is the pass's unit 2^-9 -- the integer row
+// sum (<= 17 * 255) is then simply the low 16 bits of the fp32 result.  The window keeps the sums two to a register;
+// they enter the column pass as two exact parts, sum >> 6 against weights 64 and sum & 63 against weights 1 (f16
+// subnormals again); every partial sum is an integer multiple of the unit below 2^24 units, hence exact whatever the
+// order inside the MFMA; the integer division by k^2 is one fused multiply-add and the rounding of v_cvt_pk_u8_f32,
+// verified for every reachable sum on the host.  Table part 0 = 1.0 in the window, part 1 = 64.0.
 template <int MODE>
 __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
                                                                       const Geo g, const GaussMfma gm)
@@ -119,27 +121,21 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
         reinterpret_cast<float*>(ring)[64 + lane] = wlv;
     }
     const float* tbl = reinterpret_cast<const float*>(ring);
-    // [0]: the weights' leading f16, [1]: their remainder
-    h8 bR[2][2], bG[2][2], b2[2];
+    // part 0: the weights' leading f16, part 1: their remainder (mean: 1.0 and 64.0).  ONE row-pass operand per part, for
+    // every channel: k slot i < 4 = pixel 4 grp + i of the tile's first half (pixels 16 t - 8 ..), i >= 4 = pixel
+    // 4 grp + i - 4 of its second half; output pixel r16; tap index = input pixel - output pixel + R.  The pixel bytes
+    // enter as f16 subnormals (byte * 2^-24), so these weights carry 2^15 and the column pass's 2^9.
+    // Column pass: k slot i = row 4 grp + i of the upper block (i < 4), row 4 grp + i - 4 of the lower one; output row 8 + r16.
+    h8 brow[2], b2s[2];
 #pragma unroll
-    for (int part = 0; part < 2; part++) {
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                // k slot (pixel p of this lane group's chunk, channel): input pixel 16 h + 4 grp + p - 8 of the window,
-                // output pixel r16: tap index (16 h + 4 grp + p - 8) - r16 + R
-                const float v = tbl[64 * part + 24 + 16 * h + 4 * grp + p - 8 - r16 + R];
-                bR[part][h][2 * p] = (_Float16)v; bR[part][h][2 * p + 1] = (_Float16)0.f;
-                bG[part][h][2 * p] = (_Float16)0.f; bG[part][h][2 * p + 1] = (_Float16)v;
-            }
+    for (int part = 0; part < 2; part++)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            // k slot i: row 4 grp + i of the upper block (i < 4), row 4 grp + i - 4 of the lower one; output row 8 + r16
-            const int rel = i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4);
-            b2[part][i] = (_Float16)tbl[64 * part + 24 + rel - 8 - r16 + R];
+            const int relx = (i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4)) - 8;
+            brow[part][i] = (_Float16)(tbl[64 * part + 24 + relx - r16 + R] * 32768.f);
+            const int rely = i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4);
+            b2s[part][i] = (_Float16)(tbl[64 * part + 24 + rely - 8 - r16 + R] * 512.f);
         }
-    }
     gm_wait_lds();       // the table has been read: the ring is free for the first rows
 
     // ---- addressing
@@ -203,42 +199,33 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
             if (h == 8) at = grp < 2 ? at : halo_at;
             raw[h] = *reinterpret_cast<const u32x4*>(buf + at);
         }
-        u32x4 aRG, aBA;
-        auto widen = [&](const u32x4& q, u32x4& rg, u32x4& ba) __attribute__((always_inline)) {
-            rg.x = __builtin_amdgcn_perm(0x64646464u, q.x, 0x04010400u); ba.x = __builtin_amdgcn_perm(0x64646464u, q.x, 0x04030402u);
-            rg.y = __builtin_amdgcn_perm(0x64646464u, q.y, 0x04010400u); ba.y = __builtin_amdgcn_perm(0x64646464u, q.y, 0x04030402u);
-            rg.z = __builtin_amdgcn_perm(0x64646464u, q.z, 0x04010400u); ba.z = __builtin_amdgcn_perm(0x64646464u, q.z, 0x04030402u);
-            rg.w = __builtin_amdgcn_perm(0x64646464u, q.w, 0x04010400u); ba.w = __builtin_amdgcn_perm(0x64646464u, q.w, 0x04030402u);
+        // a half's pixels as f16 pairs per channel, (pixel 0, pixel 1) and (pixel 2, pixel 3): bytes (b0, 0, b1, 0)
+        u32 aP[3][2];
+        auto pairs = [&](const u32x4& q, u32 (&pp)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                pp[c][0] = __builtin_amdgcn_perm(q.y, q.x, 0x0c040c00u + (u32)c * 0x00010001u);
+                pp[c][1] = __builtin_amdgcn_perm(q.w, q.z, 0x0c040c00u + (u32)c * 0x00010001u);
+            }
         };
-        widen(raw[0], aRG, aBA);
+        pairs(raw[0], aP);
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             if (t < ntile && MI_GM_DBG < 4) {
-                u32x4 nRG, nBA;
-                widen(raw[t + 1], nRG, nBA);
-                const h8 a0 = __builtin_bit_cast(h8, aRG), a1 = __builtin_bit_cast(h8, nRG);
-                const h8 d0 = __builtin_bit_cast(h8, aBA), d1 = __builtin_bit_cast(h8, nBA);
+                u32 nP[3][2];
+                pairs(raw[t + 1], nP);
                 f32x4 mid[3];
-                if (MODE == 0) {
-                    // (the small terms first: they are added to the start value at full precision)
-                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[1][0], c1v, 0, 0, 0);
-                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[1][0], c1v, 0, 0, 0);
-                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[1][0], c1v, 0, 0, 0);
-                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[1][1], mid[0], 0, 0, 0);
-                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[1][1], mid[1], 0, 0, 0);
-                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[1][1], mid[2], 0, 0, 0);
-                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], mid[0], 0, 0, 0);
-                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], mid[1], 0, 0, 0);
-                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], mid[2], 0, 0, 0);
-                } else {
-                    mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bR[0][0], c1v, 0, 0, 0);
-                    mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bG[0][0], c1v, 0, 0, 0);
-                    mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d0, bR[0][0], c1v, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const h8 a = __builtin_bit_cast(h8, u32x4{aP[c][0], aP[c][1], nP[c][0], nP[c][1]});
+                    if (MODE == 0) {     // (the small terms first: they are added to the start value at full precision)
+                        mid[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, brow[1], c1v, 0, 0, 0);
+                        mid[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, brow[0], mid[c], 0, 0, 0);
+                    } else {
+                        mid[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, brow[0], c1v, 0, 0, 0);
+                    }
+                    aP[c][0] = nP[c][0]; aP[c][1] = nP[c][1];
                 }
-                mid[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bR[0][1], mid[0], 0, 0, 0);
-                mid[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bG[0][1], mid[1], 0, 0, 0);
-                mid[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bR[0][1], mid[2], 0, 0, 0);
-                aRG = nRG; aBA = nBA;
                 // what the window keeps of this block's rows 4 grp .. + 3, two registers per channel: MODE 0 f16 pairs; MODE 1
                 // the integer row sums (below 2^13), two to a register
                 u32 cur[3][2];
@@ -247,9 +234,11 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                     if constexpr (MODE == 0) {
                         cur[c][0] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].x, mid[c].y}, h2));
                         cur[c][1] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{mid[c].z, mid[c].w}, h2));
-                    } else {
-                        cur[c][0] = (u32)mid[c].x | ((u32)mid[c].y << 16);
-                        cur[c][1] = (u32)mid[c].z | ((u32)mid[c].w << 16);
+                    } else {     // the accumulator started at 2^14, whose last place is the row pass's unit 2^-9: the sum is its low 16 bits
+                        // (copies first: __builtin_bit_cast of a vector ELEMENT read element 0 whatever the index, hipcc 7.2)
+                        const float m0 = mid[c][0], m1 = mid[c][1], m2 = mid[c][2], m3 = mid[c][3];
+                        cur[c][0] = __builtin_amdgcn_perm(__float_as_uint(m1), __float_as_uint(m0), 0x05040100u);
+                        cur[c][1] = __builtin_amdgcn_perm(__float_as_uint(m3), __float_as_uint(m2), 0x05040100u);
                     }
                 }
                 if (!prime) {
@@ -258,17 +247,17 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                     for (int c = 0; c < 3; c++) {
                         const u32x4 a2 = {win[t][c][0], win[t][c][1], cur[c][0], cur[c][1]};
                         if constexpr (MODE == 0) {
-                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[1], c2v, 0, 0, 0);
-                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2[0], o3[c], 0, 0, 0);
-                        } else {     // the two exact parts of the sums, sum >> 6 and sum & 63, each as 0x6400 | x = 1024 + x in f16
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2s[1], c2v, 0, 0, 0);
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2s[0], o3[c], 0, 0, 0);
+                        } else {     // the two exact parts of the sums, sum >> 6 (weights 64) and sum & 63 (weights 1), as f16 subnormals
                             u32x4 ah, al;
 #pragma unroll
                             for (int i = 0; i < 4; i++) {
-                                ah[i] = ((a2[i] >> 6) & 0x007f007fu) | 0x64006400u;
-                                al[i] = (a2[i] & 0x003f003fu) | 0x64006400u;
+                                ah[i] = (a2[i] >> 6) & 0x007f007fu;
+                                al[i] = a2[i] & 0x003f003fu;
                             }
-                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), b2[1], c2v, 0, 0, 0);
-                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), b2[0], o3[c], 0, 0, 0);
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), b2s[1], c2v, 0, 0, 0);
+                            o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), b2s[0], o3[c], 0, 0, 0);
                         }
                     }
                     u32x4 o;
@@ -371,7 +360,7 @@ static bool gauss_mfma_weights(int k, float sigma, GaussMfma* gm)
     else if ((double)cl < rest) cl = f16_value((unsigned short)(cb + 1));
     gm->wl[R] = cl;
     const double S = others + (double)gm->w[R] + (double)cl;
-    gm->c1 = (float)-(1024.0 * S + 128.0);
+    gm->c1 = -0.25f;      // the row pass works in units of 512 levels: -128 / 512
     gm->c2 = (float)(128.0 * S + MI_GM_BIAS - 0.5);
     gm->rcp = 1.f; gm->d = 0.f;
     gm->R = R;
@@ -423,13 +412,14 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
     static std::mutex mu;
     static int state[18];            // 0 unknown, 1 verified, -1 failed
     const float kk = (float)(k * k);
-    const float rcp = 1.0f / kk, d = 0.5f / kk - 0.5f;
+    const float unit = 1.0f / 32768.0f;      // the column pass leaves sum * 2^-15
+    const float rcp = 1.0f / (kk * unit), d = 0.5f / kk - 0.5f;
     {
         std::lock_guard<std::mutex> lock(mu);
         if (state[k] == 0) {
             bool ok = true;
             for (int sum = 0; sum <= 255 * k * k && ok; sum++) {
-                const float f = __builtin_fmaf((float)sum, rcp, d);
+                const float f = __builtin_fmaf((float)sum * unit, rcp, d);
                 ok = (int)nearbyintf(f) == sum / (k * k);
             }
             state[k] = ok ? 1 : -1;
@@ -438,8 +428,8 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
     }
     GaussMfma gm;
     for (int t = 0; t < 17; t++) { gm.w[t] = t < k ? 1.0f : 0.f; gm.wl[t] = t < k ? 64.0f : 0.f; }
-    gm.c1 = -1024.0f * (float)k;
-    gm.c2 = -1024.0f * 65.0f * (float)k;
+    gm.c1 = 16384.0f;      // 2^14, whose last place is the row pass's unit 2^-9: the row sum is the low 16 bits of the accumulator
+    gm.c2 = 0.f;
     gm.rcp = rcp; gm.d = d;
     gm.R = R;
     return launch_mfma<1>(gm, s, in, out, g);

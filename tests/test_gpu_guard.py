@@ -39,7 +39,7 @@ def _mean_valu(k):
         try:
             return L.mi_meanblur_u8x4_dev(i, o, w, h, b, k, None)
         finally:
-            L.mi_debug_set_tuning(b"MI_MEAN_MFMA", 15)
+            L.mi_debug_set_tuning(b"MI_MEAN_MFMA", 11)
     return call
 
 
@@ -62,7 +62,7 @@ CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_de
 CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.4 * k, 0, None))(k))
           for k in (3, 5, 7, 9, 11, 13, 15)]
 CASES += [(f"gausswide{k}", _gauss_wide(k)) for k in (7, 11, 15)]
-CASES += [("mean17", lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 17, None)), ("meanvalu15", _mean_valu(15))]
+CASES += [("mean17", lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 17, None)), ("meanvalu11", _mean_valu(11)), ("meanvalu15", _mean_valu(15))]
 
 
 @pytest.mark.parametrize("label,call", CASES, ids=[c[0] for c in CASES])

@@ -122,7 +122,7 @@ def test_mean_other_sizes(dev, golden, k):
 
 @pytest.mark.parametrize("k", [5, 7, 9, 11, 13, 15, 17])
 def test_mean_on_the_matrix_cores_is_exact(dev, golden, k):
-    """gauss_mfma_kernel<1> (the default for 15x15 and 17x17; MI_MEAN_MFMA=5 sends every size it takes through it):
+    """gauss_mfma_kernel<1> (the default for 11x11 .. 17x17; MI_MEAN_MFMA=5 sends every size it takes through it):
     integer row sums on the matrix cores, two exact f16 parts into the column pass, the division as one fused
     multiply-add -- bit-exact against the oracle on noise and on an all-white image (the largest sums), equal to the
     vector-ALU kernels, and independent of band height and row strips."""

@@ -63,7 +63,7 @@ struct GaussMfma {
 #define MI_GM_WAVES 2
 #endif
 #ifndef MI_GM_DBG
-#define MI_GM_DBG 0       // experiment builds only (wrong output): 1 = no stores, 2 = no loads, 3 = neither, 4 = loads and stores without the arithmetic, 5 = the same without the halo chunks
+#define MI_GM_DBG 0       // experiment builds only (wrong output): 1 = no stores, 2 = no loads, 3 = neither, 4 = loads and stores without the arithmetic, 5 = the same without the halo chunks, 6 = as 5 and without a band's first (priming) block: with MI_ROWS_PER_BAND=16 a plain copy in 16-row x 512-byte tiles
 #endif
 #ifndef MI_GM_BIAS
 #define MI_GM_BIAS (1.0 / 256.0)   // added before the truncating store: covers fp32 accumulation error, so that a constant image stays constant
@@ -154,14 +154,14 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     // halo: lane -> (group q = lane / 16, row r16); groups 0, 1 = chunks -2, -1; groups 2, 3 = chunks 32, 33
     const int halo_lane = delta0 + r16 * pitch + (grp < 2 ? grp - 2 : 30 + grp) * 16;
     auto request = [&](int s, int b) __attribute__((always_inline)) {     // block s of the band -> buffer b
-        if (MI_GM_DBG == 2 || MI_GM_DBG == 3) return;
+        if (MI_GM_DBG == 2 || MI_GM_DBG == 3 || (MI_GM_DBG == 6 && s == 0)) return;
         unsigned char* dst = ring + b * GM_BUF;
         const int rowoff = 16 * s * pitch;
 #pragma unroll
         for (int i = 0; i < 8; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + 1024 * i), 16,
                                                      main_lane + rowoff + 2 * i * pitch + (((c0 - 2 * i) & 31) << 4), 0, 0, 0);
-        if (MI_GM_DBG != 5)
+        if (MI_GM_DBG != 5 && MI_GM_DBG != 6)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + GM_MAIN), 16,
                                                  halo_lane + rowoff, 0, 0, 0);
     };
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     for (int s = 0; s <= n; s++) {
         const int b = s & 1;
         if (MI_GM_DBG == 2 || MI_GM_DBG == 3) {}
+        else if (MI_GM_DBG == 6) { if (s >= 1) gm_wait_vm<0>(); }
         else if (MI_GM_DBG == 5) { if (s + 1 <= n) { if (s <= 1) gm_wait_vm<8>(); else gm_wait_vm<16>(); } else gm_wait_vm<0>(); }
         else if (s + 1 <= n) { if (s <= 1 || MI_GM_DBG == 1) gm_wait_vm<9>(); else gm_wait_vm<17>(); }
         else gm_wait_vm<0>();

@@ -61,9 +61,11 @@ report(f"grayscale ({C})", "imageTools.cu:217-231", px, 8, lambda: ops.grayscale
 report(f"Sobel ({C})", ":255-285", px, 8, lambda: ops.sobel(fr, out))
 report(f"mean 3x3 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 3, out))
 report(f"mean 7x7 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 7, out), 20)
-report(f"mean 15x15 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 15, out), 20)
-report(f"mean 17x17, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 20, "sizes 17..31: no row window, the leaving row is read again")
-report(f"mean 31x31, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "sizes 17..31")
+report(f"mean 11x11, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 11, out), 20, "sizes 11..17: gauss_mfma_kernel<1>, exact")
+report(f"mean 15x15, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 15, out), 20, "sizes 11..17")
+report(f"mean 17x17, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 20, "sizes 11..17")
+report(f"mean 19x19, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 19, out), 20, "sizes 19..31: no row window, the leaving row is read again")
+report(f"mean 31x31, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "sizes 19..31")
 ops.set_tuning("MI_MEAN_PREFIX", 0)
 report(f"mean 31x31, LDS tiles (round 1's kernel, MI_MEAN_PREFIX=0) ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 10, "kept as a cross-check")
 ops.set_tuning("MI_MEAN_PREFIX", 1)

@@ -323,7 +323,7 @@ int mi_filter_strip_u8x4_dev(int filter, const void* d_in, void* d_out, int w, i
     if (rc) return rc;
     if (y_begin < 0 || y_end > h_total || y_begin >= y_end || in_rows <= 0)
         return fail(MI_ERR_INVALID_ARG, "bad row range [%d,%d) of %d", y_begin, y_end, h_total);
-    const int halo = filter_halo_rows(filter, param_i);
+    const int halo = filter_halo_rows(filter, param_i, w);
     const int need0 = std::max(0, y_begin - halo), need1 = std::min(h_total, y_end + halo);
     if (in_row0 < 0 || in_row0 > need0 || in_row0 + in_rows < need1 || in_row0 + in_rows > h_total)
         return fail(MI_ERR_INVALID_ARG, "input rows [%d,%d) do not cover the needed rows [%d,%d)",

@@ -1715,7 +1715,7 @@ int launch_sobel_pairs(void* out, int gmax, int variant, hipStream_t s)
     return hip_status(hipGetLastError(), "sobel pairs kernel launch");
 }
 
-int filter_halo_rows(int filter, int ksize)
+int filter_halo_rows(int filter, int ksize, int w)
 {
     switch (filter) {
     case MI_FILTER_GRAYSCALE: return 0;
@@ -1725,7 +1725,10 @@ int filter_halo_rows(int filter, int ksize)
     case MI_FILTER_MEAN:
     case MI_FILTER_MEDIAN: {
         const int r = ksize / 2;
-        return r <= 1 ? 1 : r + 1;  // r>1: one more row for the flat-index wrap
+        if (r <= 1) return 1;
+        // the taps are flat indices: r pixels to the side reach ceil(r / w) rows further (one row unless the
+        // image is narrower than the radius)
+        return r + (w >= r ? 1 : (r + w - 1) / w);
     }
     default: return -1;
     }

@@ -387,7 +387,7 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
 {
     const size_t pitch = (size_t)w * 4;
     int halo_sum = 0;
-    for (int k = 0; k < n_ops; k++) halo_sum += filter_halo_rows(ops[k].filter, ops[k].ksize);
+    for (int k = 0; k < n_ops; k++) halo_sum += filter_halo_rows(ops[k].filter, ops[k].ksize, w);
     // chunk: about 8 MiB of output rows, never fewer rows than the accumulated halo (so that a
     // chunk's input never reaches into rows an earlier chunk may already have overwritten when
     // `out` aliases `in`, see below)
@@ -446,7 +446,7 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
         // rows each stage must produce, back to front
         need[n_ops] = Rows{y0 + c * chunk, std::min(y1, y0 + (c + 1) * chunk)};
         for (int k = n_ops - 1; k >= 0; k--) {
-            const int halo = filter_halo_rows(ops[k].filter, ops[k].ksize);
+            const int halo = filter_halo_rows(ops[k].filter, ops[k].ksize, w);
             need[k] = Rows{std::max(0, need[k + 1].lo - halo), std::min(h, need[k + 1].hi + halo)};
         }
         out_rows[c] = need[n_ops];

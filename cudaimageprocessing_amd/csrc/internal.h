@@ -65,7 +65,8 @@ struct FilterArgs {
 int launch_filter(const FilterArgs& a);
 // argument check shared by every entry that takes a filter (kernel sizes, sigma, minimum image size)
 int check_filter(int filter, int w, int h, int ksize, float sigma);
-int filter_halo_rows(int filter, int ksize);
+// rows of halo per side; w: image width in pixels (matters only for images narrower than the radius)
+int filter_halo_rows(int filter, int ksize, int w = 1 << 30);
 // gray -> Gaussian 5x5 -> median 3x3 -> Sobel in one kernel (whole frames).
 int launch_chain(const void* in, void* out, int w, int h, int batch, float sigma, hipStream_t s);
 

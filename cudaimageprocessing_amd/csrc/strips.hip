@@ -55,7 +55,7 @@ int strip_rows(int h, int n, int i, int* y0, int* y1)
 int strip_stage_dev(void* const* d_in, void* const* d_out, int w, int h, const int* devices, int n, int pad,
                     int filter, int ksize, float sigma)
 {
-    const int halo = filter_halo_rows(filter, ksize);
+    const int halo = filter_halo_rows(filter, ksize, w);
     if (halo < 0) return fail(MI_ERR_INVALID_ARG, "unknown filter %d", filter);
     if (halo > pad && n > 1) return fail(MI_ERR_INVALID_ARG, "the stage needs %d halo rows, the buffers have %d pad rows", halo, pad);
     const size_t pitch = (size_t)w * 4;

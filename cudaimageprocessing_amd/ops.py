@@ -116,10 +116,15 @@ def filter_strip(filter_id, strip_in, out, w, h_total, in_row0, y_begin, y_end, 
     return out
 
 
-def halo_rows(filter_id, ksize=3):
+def halo_rows(filter_id, ksize=3, w=None):
+    """Rows of halo a strip needs per side; `w` (pixels) only matters for an image narrower than the radius, whose
+    flat-index taps reach ceil(r / w) rows further instead of one."""
     n = lib().mi_filter_halo_rows(int(filter_id), int(ksize))
     if n < 0:
         raise ValueError(f"unknown filter {filter_id}")
+    r = int(ksize) // 2
+    if w is not None and n > 1 and int(w) < r:
+        n = r + -(-r // int(w))
     return n
 
 

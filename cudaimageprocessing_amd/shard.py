@@ -93,7 +93,7 @@ class StripPlan:
         """One filter over the strip: neighbour exchange of `halo` rows, interior rows filtered while
         the halos travel, then the two edge bands.  Returns the output strip (a view of the other
         buffer, which becomes the current one)."""
-        halo = _halo_rows(filter_id, ksize)
+        halo = _halo_rows(filter_id, ksize, self.w)
         if halo > self.pad:
             raise ValueError(f"stage needs {halo} halo rows, the plan was made for {self.pad}")
         src, dst = self.bufs[self.cur], self.bufs[self.cur ^ 1]
@@ -152,15 +152,18 @@ def strip_filter(strip, filter_id, w, h_total, rank, world, ksize=3, sigma=0.0, 
                        (lambda f, k, s: compute) if compute else None)
 
 
-def _halo_rows(filter_id, ksize):
+def _halo_rows(filter_id, ksize, w=None):
     """Rows of halo per side (mirrors mi_filter_halo_rows; kept in Python so that host logic
-    can be tested without the library)."""
+    can be tested without the library).  `w`: image width, which matters only below the radius (the taps are
+    flat indices, so r pixels to the side reach ceil(r / w) rows further)."""
     if filter_id == _lib.FILTER_GRAYSCALE:
         return 0
     if filter_id == _lib.FILTER_SOBEL:
         return 1
     r = ksize // 2
-    return 1 if r <= 1 else r + 1
+    if r <= 1:
+        return 1
+    return r + (1 if w is None or w >= r else -(-r // w))
 
 
 def strip_chain(strip, stages, w, h_total, rank, world, group=None, compute_factory=None):
@@ -170,7 +173,7 @@ def strip_chain(strip, stages, w, h_total, rank, world, group=None, compute_fact
         raise RuntimeError("strip filtering needs CUDA/HIP tensors (no CPU fallback)")
     y0, y1 = strip_range(h_total, world, rank)
     assert strip.shape[0] == y1 - y0 and strip.shape[1] == w, "strip does not match strip_range()"
-    pad = max([_halo_rows(f, k) for f, k, _ in stages] + [0])
+    pad = max([_halo_rows(f, k, w) for f, k, _ in stages] + [0])
     plan = StripPlan(w, h_total, rank, world, pad, strip.device, group)
     plan.strip().copy_(strip)
     return plan.run_chain(stages, compute_factory)

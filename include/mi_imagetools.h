@@ -133,7 +133,10 @@ int mi_chain_gray_gauss5_median3_sobel_u8x4_dev(const void *d_in, void *d_out, i
 int mi_filter_strip_u8x4_dev(int filter, const void *d_in, void *d_out, int w, int h_total,
                              int in_row0, int in_rows, int y_begin, int y_end, int param_i,
                              float param_f, void *stream);
-/* Rows of halo a strip needs above and below for `filter` (0 for grayscale). */
+/* Rows of halo a strip needs above and below for `filter` (0 for grayscale; r + 1 for a stencil of radius r > 1,
+ * whose flat-index taps reach into the next row).  For an image narrower than the radius (w < r) the taps reach
+ * ceil(r / w) rows further instead of one: such a strip needs r + ceil(r / w) rows, and mi_filter_strip_u8x4_dev
+ * rejects a strip whose input rows do not cover them. */
 int mi_filter_halo_rows(int filter, int param_i);
 
 /* Synthetic input generator used by the benchmarks and tests (not in the reference):

@@ -425,6 +425,34 @@ def test_wide_mean_strips_tiles_and_oracle(dev, golden, k):
         assert torch.equal(out, whole[y0:y1]), (y0, y1)
 
 
+def test_strips_of_images_narrower_than_the_radius(dev, golden):
+    """Width 4 (and 3, 5, 7: the 64-bit-address policy) with radii up to 11: the flat-index taps reach
+    ceil(r / w) rows up and down, so a strip needs r + ceil(r / w) rows of halo (ops.halo_rows(.., w)); with them
+    the stitched strips equal the single launch, which equals the oracle; with only r + 1 the strip entry refuses."""
+    for w, h in ((4, 130), (3, 200), (5, 150), (7, 120)):
+        img = ops.synth(w + h, w, h)
+        for filt, k, sigma in ((_lib.FILTER_MEAN, 17, 0.0), (_lib.FILTER_MEAN, 13, 0.0), (_lib.FILTER_MEAN, 23, 0.0),
+                               (_lib.FILTER_GAUSSIAN, 15, 9.0), (_lib.FILTER_GAUSSIAN, 9, 4.0), (_lib.FILTER_MEDIAN, 5, 0.0)):
+            if k * k > w * h:
+                continue
+            whole = ops.mean_blur(img, k) if filt == _lib.FILTER_MEAN else (
+                ops.gaussian_blur(img, k, sigma) if filt == _lib.FILTER_GAUSSIAN else ops.median_blur(img, k))
+            if filt == _lib.FILTER_MEAN:
+                assert np.array_equal(host(whole), golden.meanblur(host(img), k)), (w, h, k)
+            halo = ops.halo_rows(filt, k, w)
+            assert halo == k // 2 + -(-(k // 2) // w)
+            for y0, y1 in ((0, 41), (41, 42), (42, 97), (97, h)):
+                r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+                out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+                ops.filter_strip(filt, img[r0:r1].contiguous(), out, w, h, r0, y0, y1, k, sigma)
+                assert torch.equal(out, whole[y0:y1]), (w, h, filt, k, y0, y1)
+            if halo > k // 2 + 1:
+                short = k // 2 + 1
+                out = torch.empty((10, w, 4), dtype=torch.uint8, device=dev)
+                with pytest.raises(Exception):
+                    ops.filter_strip(filt, img[60 - short:70 + short].contiguous(), out, w, h, 60 - short, 60, 70, k, sigma)
+
+
 def test_wide_mean_odd_shapes_equal_the_tile_kernel(dev):
     """Shapes around the prefix-sum march's strip width (224 pixels), unaligned widths (the 64-bit-address
     policy), batches, a very wide image and images smaller than the kernel: same bytes as the LDS-tile

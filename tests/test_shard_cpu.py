@@ -120,3 +120,7 @@ def test_partitions():
     for f, k in ((_lib.FILTER_GRAYSCALE, 0), (_lib.FILTER_SOBEL, 3), (_lib.FILTER_MEAN, 3), (_lib.FILTER_MEDIAN, 5),
                  (_lib.FILTER_GAUSSIAN, 15), (_lib.FILTER_GAUSSIAN, 3)):
         assert shard._halo_rows(f, k) == _lib.lib().mi_filter_halo_rows(f, k)
+    # an image narrower than the radius: the flat-index taps reach ceil(r / w) rows further, not one
+    assert shard._halo_rows(_lib.FILTER_MEAN, 17, 4) == 10 and shard._halo_rows(_lib.FILTER_MEAN, 17, 8) == 9
+    assert shard._halo_rows(_lib.FILTER_MEAN, 31, 3) == 20 and shard._halo_rows(_lib.FILTER_GAUSSIAN, 15, 3) == 10
+    assert shard._halo_rows(_lib.FILTER_MEDIAN, 5, 3) == 3 and shard._halo_rows(_lib.FILTER_SOBEL, 3, 3) == 1

@@ -46,7 +46,7 @@ for it in range(cases):
             print(f"case {it}: {'mean' if mean else 'gauss'} k={k} sigma={sigma} {w}x{h} batch {b} frame {f} kind {kind} rpb {rpb}: max diff {diff.max()} at {np.argwhere(diff == diff.max())[0].tolist()}", flush=True)
     # a random split into row strips of frame 0
     filt = _lib.FILTER_MEAN if mean else _lib.FILTER_GAUSSIAN
-    halo = ops.halo_rows(filt, k)
+    halo = ops.halo_rows(filt, k, w)
     cuts = sorted(set([0, h] + [int(x) for x in rng.integers(1, h, int(rng.integers(0, 4)))]))
     pieces = []
     for y0, y1 in zip(cuts[:-1], cuts[1:]):

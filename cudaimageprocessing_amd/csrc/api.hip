@@ -42,7 +42,7 @@ const Knob KNOBS[] = {
     {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_FUSED_SPECTRAL", &Tuning::fft_fused_spectral},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
-    {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_GAUSS_MFMA", &Tuning::gauss_mfma}, {"MI_MEAN_MFMA", &Tuning::mean_mfma}, {"MI_GAUSS_DIRECT_WIN", &Tuning::gauss_direct_win}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
+    {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_GAUSS_MFMA", &Tuning::gauss_mfma}, {"MI_GAUSS_MFMA_MAX", &Tuning::gauss_mfma_max}, {"MI_MEAN_MFMA", &Tuning::mean_mfma}, {"MI_MEAN_MFMA_MAX", &Tuning::mean_mfma_max}, {"MI_GAUSS_DIRECT_WIN", &Tuning::gauss_direct_win}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
 };
 Tuning& tuning_rw()
 {
@@ -159,7 +159,7 @@ static int run_frames(int filter, const void* in, void* out, int w, int h, int b
     // kernel size 1 is the identity on the write set; the generic paths handle it
     FilterArgs a;
     a.filter = filter;
-    if (filter == MI_FILTER_GAUSSIAN && (ksize == 1 || ksize > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    if (filter == MI_FILTER_GAUSSIAN && (ksize == 1 || ksize > 31)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
     a.in = in; a.out = out; a.w = w; a.h_total = h; a.batch = batch;
     a.in_row0 = 0; a.in_rows = h; a.y_begin = 0; a.y_end = h;
     a.ksize = ksize; a.sigma = sigma; a.stream = (hipStream_t)stream;
@@ -332,7 +332,7 @@ int mi_filter_strip_u8x4_dev(int filter, const void* d_in, void* d_out, int w, i
         return fail(MI_ERR_OVERLAP, "device-tier in/out buffers overlap");
     FilterArgs a;
     a.filter = filter;
-    if (filter == MI_FILTER_GAUSSIAN && (param_i == 1 || param_i > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+    if (filter == MI_FILTER_GAUSSIAN && (param_i == 1 || param_i > 31)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
     a.in = d_in; a.out = d_out; a.w = w; a.h_total = h_total; a.batch = 1;
     a.in_row0 = in_row0; a.in_rows = in_rows; a.y_begin = y_begin; a.y_end = y_end;
     a.ksize = param_i; a.sigma = param_f; a.stream = (hipStream_t)stream;

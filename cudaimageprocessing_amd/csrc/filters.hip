@@ -1945,6 +1945,26 @@ int launch_filter(const FilterArgs& a)
     g.out_frame_stride = out_frame;
     const int rows = a.y_end - a.y_begin;
 
+    // separable Gaussians 17x17 .. 31x31: on the matrix cores (gauss_mfma_wide_kernel, within one level like the smaller
+    // ones) where that applies, else the direct kernels (bit-exact, slower)
+    if (a.filter == MI_FILTER_GAUSSIAN && a.ksize > 15) {
+        if (aligned && a.ksize <= std::min(31, tuning().gauss_mfma_max) && tuning().gauss_mfma) {
+            const int rc = launch_gauss_mfma(a.ksize, a.sigma, a.stream, in, out, g);
+            if (rc != 1) return rc;
+        }
+        FilterArgs d = a;
+        d.filter = MI_FILTER_GAUSSIAN_DIRECT;
+        return launch_filter(d);
+    }
+
+    // mean blur 11x11 .. 31x31 on the matrix cores (exact; gauss_mfma.hip; MI_MEAN_MFMA moves the threshold,
+    // MI_MEAN_MFMA_MAX the largest size)
+    if (a.filter == MI_FILTER_MEAN && aligned && tuning().mean_mfma > 0 && a.ksize >= tuning().mean_mfma && a.ksize >= 5 &&
+        a.ksize <= std::min(31, tuning().mean_mfma_max)) {
+        const int rc = launch_mean_mfma(a.ksize, a.stream, in, out, g);
+        if (rc != 1) return rc;
+    }
+
     // generic one-thread-per-pixel kernels
     const bool direct_march = a.filter == MI_FILTER_GAUSSIAN_DIRECT && a.ksize >= 3 && a.ksize <= 7;
     const bool direct = a.filter == MI_FILTER_GAUSSIAN_DIRECT && !direct_march;
@@ -2033,12 +2053,6 @@ int launch_filter(const FilterArgs& a)
             }
         }
         return hip_status(hipGetLastError(), "generic filter kernel launch");
-    }
-
-    // mean blur 11x11 .. 17x17 on the matrix cores (exact; gauss_mfma.hip; MI_MEAN_MFMA moves the threshold)
-    if (a.filter == MI_FILTER_MEAN && aligned && tuning().mean_mfma > 0 && a.ksize >= tuning().mean_mfma && a.ksize >= 5 && a.ksize <= 17) {
-        const int rc = launch_mean_mfma(a.ksize, a.stream, in, out, g);
-        if (rc != 1) return rc;
     }
 
     // wave-march kernels

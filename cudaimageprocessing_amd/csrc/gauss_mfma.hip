@@ -1,4 +1,5 @@
-// gauss_mfma.hip -- separable Gaussian blur 7x7 .. 17x17 with both passes on the matrix cores (gfx950).
+// gauss_mfma.hip -- separable Gaussian blur 7x7 .. 31x31 and exact mean blur 5x5 .. 31x31 with both passes on the matrix
+// cores (gfx950).  gauss_mfma_kernel: radius <= 8; gauss_mfma_wide_kernel (further down): radius 9 .. 15.
 //
 // Reference: imageGaussianBlur, /root/reference/kernels/imageTools.cu:287-311 (direct k x k fp32 sum, truncating
 // store).  The separable form is allowed +-1 level; gauss_wide_kernel (filters.hip) meets it in
@@ -302,6 +303,226 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sizes 19x19 .. 31x31 (radius 9 .. 15): the same scheme on ALIGNED 16-pixel halves and 16-row blocks.  An output tile
+// needs the halves t - 1, t, t + 1 and the blocks above, at and below it, so each pass of a tile is three
+// v_mfma_f32_16x16x16_f16 per part (a lane's 16-byte chunk IS the K = 16 operand of a channel after the two v_perm_b32;
+// the row pass's result IS the column pass's operand for that block), the window keeps the row pass of TWO earlier
+// blocks, the halo is 16 pixels on each side (two DMA instructions a block), and a band of n output blocks loads n + 2.
+struct GaussMfmaWide {
+    float w[31];     // as GaussMfma
+    float wl[31];
+    float c1, c2, rcp, d;
+    int R;
+    int ob_first;    // first output block of the launch: output block b holds rows 16 b .. 16 b + 15
+    int nob;
+    int bpb;
+};
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2v __attribute__((ext_vector_type(2)));
+#define GW_BUF (GM_MAIN + 2048)            // + 16 rows x (16 pixels left, 16 pixels right)
+
+template <int MODE>
+__global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
+                                                                const Geo g, const GaussMfmaWide gm)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const WaveJob j = wave_job(g);
+    if (!j.valid) return;
+    const int lane = j.lane, r16 = lane & 15, grp = lane >> 4;
+    const int R = gm.R, W = g.W, pitch = W * 4;
+    const int cx0 = j.strip * 128;
+    const int ntile = min(8, (W - cx0 + 15) >> 4);
+    const int ob0 = gm.ob_first + j.band * gm.bpb;
+    const int n = min(gm.bpb, gm.ob_first + gm.nob - ob0);
+    const int ya = max(g.y_begin, 16 * ob0), yb = min(g.y_end, 16 * (ob0 + n));
+
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * GW_BUF];
+
+    // ---- Toeplitz operands from a zero-padded weight table in LDS: tbl[128 part + 32 + t] = w[t]
+    {
+        float wv = 0.f, wlv = 0.f;
+#pragma unroll
+        for (int t = 0; t < 31; t++) { wv = (lane == 32 + t) ? gm.w[t] : wv; wlv = (lane == 32 + t) ? gm.wl[t] : wlv; }
+        float* T = reinterpret_cast<float*>(ring);
+        T[lane] = wv; T[64 + lane] = 0.f;
+        T[128 + lane] = wlv; T[192 + lane] = 0.f;
+    }
+    const float* tbl = reinterpret_cast<const float*>(ring);
+    // operand d (0, 1, 2 = the half / block before, at, after the output's): k slot i = element 4 grp + i of it, output
+    // element r16; tap index = 16 (d - 1) + 4 grp + i - r16 + R.  The same index serves rows and columns.
+    h4 brow[2][3], bcol[2][3];
+#pragma unroll
+    for (int part = 0; part < 2; part++)
+#pragma unroll
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float wt = tbl[128 * part + 32 + 16 * (d - 1) + 4 * grp + i - r16 + R];
+                brow[part][d][i] = (MODE == 1 && part == 1) ? (_Float16)0.f : (_Float16)(wt * 32768.f);
+                bcol[part][d][i] = (_Float16)(wt * 512.f);
+            }
+    gm_wait_lds();
+
+    // ---- addressing (as gauss_mfma_kernel, with input block s of the band = rows 16 (ob0 - 1 + s) ..)
+    const u32* in = in_ + (i64)j.frame * g.in_frame_stride;
+    u32* out = out_ + (i64)j.frame * g.out_frame_stride;
+    const i64 fmin = (i64)(16 * (ob0 - 1)) * W + cx0 - 16;
+    const i64 base = fmin > g.in_lo ? fmin : g.in_lo;
+    i64 bytes = (g.in_hi - base) * 4;
+    bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFF00LL ? 0x7FFFFF00LL : bytes);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
+    const int delta0 = (int)((fmin + 16 - base) * 4);            // byte offset of (row 16 (ob0 - 1), pixel cx0)
+    const int hi = lane >> 5, slot = lane & 31;
+    const int c0 = (slot - hi) & 31;
+    const int main_lane = delta0 + hi * pitch;
+    const int halo_lane = delta0 + r16 * pitch + (grp - 4) * 16;  // left: chunks -4 .. -1 of row r16; right: + 36 chunks
+    auto request = [&](int s, int b) __attribute__((always_inline)) {
+        unsigned char* dst = ring + b * GW_BUF;
+        const int rowoff = 16 * s * pitch;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + 1024 * i), 16,
+                                                     main_lane + rowoff + 2 * i * pitch + (((c0 - 2 * i) & 31) << 4), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + GM_MAIN), 16,
+                                                 halo_lane + rowoff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + GM_MAIN + 1024), 16,
+                                                 halo_lane + rowoff + 36 * 16, 0, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((i64)ya * W - g.out_origin)), 0,
+                                                                        max(yb - ya, 0) * pitch, 0x00020000);
+    const int st_px = cx0 + 4 * slot;
+    const int st_lane = st_px < W ? hi * pitch + st_px * 4 : (int)0x80000000;
+    const bool st_first = st_px == 0, st_last = st_px + 4 == W;
+
+    const int kap = (grp + r16) & 31;      // chunk 4 h + grp of row r16 sits in slot (kap + 4 h) % 32
+    const int rd_row = r16 * 512;
+    const f32x4 c1v = {gm.c1, gm.c1, gm.c1, gm.c1}, c2v = {gm.c2, gm.c2, gm.c2, gm.c2};
+    u32 w1[8][3][2], w2[8][3][2];          // the row pass of the previous block and of the one before it
+
+    request(0, 0);
+    request(1, 1);
+    for (int s = 0; s <= n + 1; s++) {
+        const int b = s & 1;
+        if (s <= n) { if (s <= 2) gm_wait_vm<10>(); else gm_wait_vm<18>(); }
+        else gm_wait_vm<0>();
+        unsigned char* buf = ring + b * GW_BUF;
+
+        // half h (-1 .. 8) of the block's row r16, pixels 16 h + 4 grp .. + 3, as f16 pairs per channel
+        auto half = [&](int h, u32 (&pp)[3][2]) __attribute__((always_inline)) {
+            const int at = h < 0 ? GM_MAIN + lane * 16 : h >= 8 ? GM_MAIN + 1024 + lane * 16 : rd_row + (((kap + 4 * h) & 31) << 4);
+            const u32x4 q = *reinterpret_cast<const u32x4*>(buf + at);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                pp[c][0] = __builtin_amdgcn_perm(q.y, q.x, 0x0c040c00u + (u32)c * 0x00010001u);
+                pp[c][1] = __builtin_amdgcn_perm(q.w, q.z, 0x0c040c00u + (u32)c * 0x00010001u);
+            }
+        };
+        u32 pm[3][2], p0[3][2], pn[3][2];
+        half(-1, pm);
+        half(0, p0);
+        half(1, pn);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (t < ntile) {
+                u32 pf[3][2];          // the half after next, fetched before this tile's results overwrite chunk 4 t + grp
+                if (t + 1 < ntile) half(t + 2, pf);
+                f32x4 mid[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const h4 am = __builtin_bit_cast(h4, u32x2v{pm[c][0], pm[c][1]});
+                    const h4 a0 = __builtin_bit_cast(h4, u32x2v{p0[c][0], p0[c][1]});
+                    const h4 an = __builtin_bit_cast(h4, u32x2v{pn[c][0], pn[c][1]});
+                    f32x4 m = c1v;
+                    if (MODE == 0) {
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(am, brow[1][0], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, brow[1][1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(an, brow[1][2], m, 0, 0, 0);
+                    }
+                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(am, brow[0][0], m, 0, 0, 0);
+                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, brow[0][1], m, 0, 0, 0);
+                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(an, brow[0][2], m, 0, 0, 0);
+                    mid[c] = m;
+                }
+                u32 cur[3][2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float m0 = mid[c][0], m1 = mid[c][1], m2 = mid[c][2], m3 = mid[c][3];
+                    if constexpr (MODE == 0) {
+                        cur[c][0] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{m0, m1}, h2));
+                        cur[c][1] = __builtin_bit_cast(u32, __builtin_convertvector(f32x2v{m2, m3}, h2));
+                    } else {
+                        cur[c][0] = __builtin_amdgcn_perm(__float_as_uint(m1), __float_as_uint(m0), 0x05040100u);
+                        cur[c][1] = __builtin_amdgcn_perm(__float_as_uint(m3), __float_as_uint(m2), 0x05040100u);
+                    }
+                }
+                if (s >= 2) {
+                    f32x4 o3[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const u32x2v blk[3] = {{w2[t][c][0], w2[t][c][1]}, {w1[t][c][0], w1[t][c][1]}, {cur[c][0], cur[c][1]}};
+                        f32x4 o = c2v;
+                        if constexpr (MODE == 0) {
+#pragma unroll
+                            for (int d = 0; d < 3; d++) o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, blk[d]), bcol[1][d], o, 0, 0, 0);
+#pragma unroll
+                            for (int d = 0; d < 3; d++) o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, blk[d]), bcol[0][d], o, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < 3; d++) {
+                                const u32x2v ah = {(blk[d][0] >> 6) & 0x007f007fu, (blk[d][1] >> 6) & 0x007f007fu};
+                                const u32x2v al = {blk[d][0] & 0x003f003fu, blk[d][1] & 0x003f003fu};
+                                o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, ah), bcol[1][d], o, 0, 0, 0);
+                                o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, al), bcol[0][d], o, 0, 0, 0);
+                            }
+                        }
+                        o3[c] = o;
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        u32 v = 0xFF000000u;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float f = MODE == 0 ? o3[c][i] : __builtin_fmaf(o3[c][i], gm.rcp, gm.d);
+                            v = __builtin_amdgcn_cvt_pk_u8_f32(f, c, v);
+                        }
+                        o[i] = v;
+                    }
+                    // output row r16 of the block, pixels 16 t + 4 grp .. + 3: chunk 4 t + grp -- this lane's own, already read
+                    *reinterpret_cast<u32x4*>(buf + rd_row + (((kap + 4 * t) & 31) << 4)) = o;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        w2[t][c][q] = w1[t][c][q]; w1[t][c][q] = cur[c][q];
+                        pm[c][q] = p0[c][q]; p0[c][q] = pn[c][q]; pn[c][q] = pf[c][q];
+                    }
+            }
+        }
+        if (s >= 2) {
+            const int y0 = 16 * (ob0 + s - 2);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int r = 2 * i + hi;
+                u32x4 v = *reinterpret_cast<const u32x4*>(buf + r * 512 + (((slot + r) & 31) << 4));
+                const int y = y0 + r;
+                const bool rowok = y >= 1 && y <= g.H - 2;
+                v.x = (rowok && !st_first) ? v.x : 0u;
+                v.y = rowok ? v.y : 0u;
+                v.z = rowok ? v.z : 0u;
+                v.w = (rowok && !st_last) ? v.w : 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + 2 * i - ya) * pitch, 0, 2);
+            }
+        }
+        gm_wait_lds();
+        if (s + 2 <= n + 1) request(s + 2, b);
+    }
+#endif
+}
+
 // fp32 -> f16 bit pattern, round to nearest even (host side; positive finite values below 65504)
 static unsigned short f16_bits(float f)
 {
@@ -335,15 +556,16 @@ static float f16_value(unsigned short h)
     return f;
 }
 
-// f16 weights for gauss_mfma_kernel; false when the kernel does not apply
-static bool gauss_mfma_weights(int k, float sigma, GaussMfma* gm)
+// f16 weights for gauss_mfma_kernel (NW = 17) and gauss_mfma_wide_kernel (NW = 31); false when the kernel does not apply
+template <class GM, int NW>
+static bool gauss_mfma_weights(int k, float sigma, GM* gm)
 {
     const int R = k / 2;
-    if (R < 1 || R > 8) return false;
+    if (k % 2 == 0 || R < 1 || 2 * R + 1 > NW) return false;
     float w[MI_MAX_KERNEL_SIZE];
     gaussian_kernel_1d(k, sigma, w);
     double others = 0.0;
-    for (int t = 0; t < 17; t++) gm->w[t] = gm->wl[t] = 0.f;
+    for (int t = 0; t < NW; t++) gm->w[t] = gm->wl[t] = 0.f;
     for (int t = 0; t < k; t++) {
         if (t == R) continue;
         gm->w[t] = f16_value(f16_bits(w[t]));
@@ -396,22 +618,53 @@ static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Ge
     return hip_status(hipGetLastError(), "matrix-core filter kernel launch");
 }
 
+// The wide form: output block b holds rows 16 b .. 16 b + 15
+template <int MODE>
+static int launch_mfma_wide(GaussMfmaWide& gm, hipStream_t s, const u32* in, u32* out, Geo g)
+{
+    const int W = g.W;
+    const int ob_first = g.y_begin / 16, ob_last = (g.y_end - 1) / 16;
+    gm.ob_first = ob_first;
+    gm.nob = ob_last - ob_first + 1;
+    if (gm.nob <= 0) return 0;
+    g.strips = (W + 127) / 128;
+    int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : 8;
+    if (tuning().rows_per_band <= 0)
+        while (bpb > 1 && (i64)g.batch * g.strips * ((gm.nob + bpb - 1) / bpb) < 4096) bpb >>= 1;
+    while (bpb > 1 && (i64)(bpb + 3) * 16 * W * 4 > (1LL << 30)) bpb >>= 1;
+    if ((i64)(bpb + 3) * 16 * W * 4 > (1LL << 30)) return 1;
+    gm.bpb = bpb;
+    g.rows_per_band = 16 * bpb;
+    g.bands = (gm.nob + bpb - 1) / bpb;
+    const i64 total = (i64)g.batch * g.bands * g.strips;
+    if (total > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
+    g.total_waves = (int)total;
+    g.xcd_remap = 1;
+    gauss_mfma_wide_kernel<MODE><<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    return hip_status(hipGetLastError(), "matrix-core filter kernel launch");
+}
+
 int launch_gauss_mfma(int k, float sigma, hipStream_t s, const u32* in, u32* out, Geo g)
 {
+    if (k > 17) {
+        GaussMfmaWide gw;
+        if (!gauss_mfma_weights<GaussMfmaWide, 31>(k, sigma, &gw)) return 1;
+        return launch_mfma_wide<0>(gw, s, in, out, g);
+    }
     GaussMfma gm;
-    if (!gauss_mfma_weights(k, sigma, &gm)) return 1;
+    if (!gauss_mfma_weights<GaussMfma, 17>(k, sigma, &gm)) return 1;
     return launch_mfma<0>(gm, s, in, out, g);
 }
 
-// Mean blur k x k, 5 <= k <= 17, exact.  rcp and d: nearest(sum * rcp + d) == sum / (k * k) for every sum a window of
+// Mean blur k x k, 5 <= k <= 31, exact.  rcp and d: nearest(sum * rcp + d) == sum / (k * k) for every sum a window of
 // bytes can reach, verified here once per size with the device's own operations (one fused multiply-add in fp32,
 // round to nearest even); 1 when no such pair is found (the caller falls back).
 int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
 {
     const int R = k / 2;
-    if (k % 2 == 0 || R < 1 || R > 8) return 1;
+    if (k % 2 == 0 || R < 1 || R > 15) return 1;
     static std::mutex mu;
-    static int state[18];            // 0 unknown, 1 verified, -1 failed
+    static int state[32];            // 0 unknown, 1 verified, -1 failed
     const float kk = (float)(k * k);
     const float unit = 1.0f / 32768.0f;      // the column pass leaves sum * 2^-15
     const float rcp = 1.0f / (kk * unit), d = 0.5f / kk - 0.5f;
@@ -426,6 +679,12 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
             state[k] = ok ? 1 : -1;
         }
         if (state[k] < 0) return 1;
+    }
+    if (k > 17) {
+        GaussMfmaWide gw;
+        for (int t = 0; t < 31; t++) { gw.w[t] = t < k ? 1.0f : 0.f; gw.wl[t] = t < k ? 64.0f : 0.f; }
+        gw.c1 = 16384.0f; gw.c2 = 0.f; gw.rcp = rcp; gw.d = d; gw.R = R;
+        return launch_mfma_wide<1>(gw, s, in, out, g);
     }
     GaussMfma gm;
     for (int t = 0; t < 17; t++) { gm.w[t] = t < k ? 1.0f : 0.f; gm.wl[t] = t < k ? 64.0f : 0.f; }

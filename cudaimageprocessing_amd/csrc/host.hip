@@ -456,7 +456,7 @@ int host_run_ops_rows(const uint8_t* in, uint8_t* out, int w, int h, const mi_op
         for (int k = 0; k < n_ops && rc == MI_OK && e == hipSuccess; k++) {
             FilterArgs a;
             a.filter = ops[k].filter;
-            if (a.filter == MI_FILTER_GAUSSIAN && (ops[k].ksize == 1 || ops[k].ksize > 15)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
+            if (a.filter == MI_FILTER_GAUSSIAN && (ops[k].ksize == 1 || ops[k].ksize > 31)) a.filter = MI_FILTER_GAUSSIAN_DIRECT;
             a.in = s.dev[cur]; a.out = s.dev[cur ^ 1]; a.w = w; a.h_total = h; a.batch = 1;
             a.in_row0 = need[k].lo; a.in_rows = need[k].hi - need[k].lo;
             a.y_begin = need[k + 1].lo; a.y_end = need[k + 1].hi;

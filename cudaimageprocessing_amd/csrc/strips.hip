@@ -97,7 +97,7 @@ int strip_stage_dev(void* const* d_in, void* const* d_out, int w, int h, const i
         auto run = [&](int in_row0, int in_rows, int yb, int ye) {
             FilterArgs f;
             f.filter = filter;
-            if (filter == MI_FILTER_GAUSSIAN && (ksize == 1 || ksize > 15)) f.filter = MI_FILTER_GAUSSIAN_DIRECT;
+            if (filter == MI_FILTER_GAUSSIAN && (ksize == 1 || ksize > 31)) f.filter = MI_FILTER_GAUSSIAN_DIRECT;
             f.in = src + (size_t)(pad + (in_row0 - y0)) * pitch;
             f.out = dst + (size_t)(yb - y0) * pitch;
             f.w = w; f.h_total = h; f.batch = 1;

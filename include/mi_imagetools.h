@@ -90,9 +90,11 @@ int mi_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, vo
  * mode MI_GAUSS_SEPARABLE: row pass then column pass with 1-D weights (max |delta| <= 1 LSB
  *   against the reference's direct 2-D sum, which truncates float->u8, imageTools.cu:306-308);
  * mode MI_GAUSS_DIRECT: the reference's k x k sum in its own order, bit-exact, slower.
- * kernel_size: odd, 1..MI_MAX_KERNEL_SIZE_ANY; sizes above 15 always take the direct form.
- * (Separable sizes 7..15 on aligned images run both passes on the matrix cores, csrc/gauss_mfma.hip;
- * the same bytes for any band, strip or batch decomposition.) */
+ * kernel_size: odd, 1..MI_MAX_KERNEL_SIZE_ANY; sizes above 31 always take the direct form, and so do separable
+ * sizes 17..31 on images the matrix-core kernels do not take (width not a multiple of 4, buffers not 16-byte aligned).
+ * (Separable sizes 7..31 on aligned images run both passes on the matrix cores, csrc/gauss_mfma.hip;
+ * the same bytes for any band, strip or batch decomposition.  Round 2 ran 17..31 in the direct form whatever the
+ * mode: MI_GAUSS_MFMA_MAX=15 brings that back.) */
 #define MI_GAUSS_SEPARABLE 0
 #define MI_GAUSS_DIRECT 1
 int mi_gaussian_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,

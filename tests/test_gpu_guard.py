@@ -62,6 +62,8 @@ CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_de
 CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.4 * k, 0, None))(k))
           for k in (3, 5, 7, 9, 11, 13, 15)]
 CASES += [(f"gausswide{k}", _gauss_wide(k)) for k in (7, 11, 15)]
+CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, k, None))(k)) for k in (19, 31)]
+CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.2 * k, 0, None))(k)) for k in (17, 23, 31)]
 CASES += [("mean17", lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 17, None)), ("meanvalu11", _mean_valu(11)), ("meanvalu15", _mean_valu(15))]
 
 

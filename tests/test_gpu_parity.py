@@ -120,20 +120,21 @@ def test_mean_other_sizes(dev, golden, k):
     assert np.array_equal(host(ops.mean_blur(to_dev(white, dev), k)), golden.meanblur(white, k))
 
 
-@pytest.mark.parametrize("k", [5, 7, 9, 11, 13, 15, 17])
+@pytest.mark.parametrize("k", [5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
 def test_mean_on_the_matrix_cores_is_exact(dev, golden, k):
-    """gauss_mfma_kernel<1> (the default for 11x11 .. 17x17; MI_MEAN_MFMA=5 sends every size it takes through it):
+    """gauss_mfma_kernel<1> and, from 19x19, gauss_mfma_wide_kernel<1> (the default for 11x11 .. 31x31; MI_MEAN_MFMA=5
+    sends every size they take through them):
     integer row sums on the matrix cores, two exact f16 parts into the column pass, the division as one fused
     multiply-add -- bit-exact against the oracle on noise and on an all-white image (the largest sums), equal to the
     vector-ALU kernels, and independent of band height and row strips."""
     with ops.tuning(MI_MEAN_MFMA=5):
-        for (w, h) in ((516, 75), (128, 64), (64, 48), (260, 131), (8, 40), (20, 33)):
+        for (w, h) in ((516, 75), (128, 64), (64, 48), (260, 131), (8, 40), (20, 33), (8, 140), (132, 17)):
             if k * k > w * h:
                 continue
             for img in (S.synth_image(k + w, w, h), np.full((h, w, 4), 255, np.uint8)):
                 d = to_dev(img, dev)
                 got = ops.mean_blur(d, k)
-                assert np.array_equal(host(got), golden.meanblur(img, k)), (k, w, h)
+                assert np.array_equal(host(got), golden.meanblur(img, k, threads=8)), (k, w, h)
                 with ops.tuning(MI_MEAN_MFMA=0):
                     assert torch.equal(ops.mean_blur(d, k), got), (k, w, h)
         w, h = 1000, 203
@@ -413,16 +414,19 @@ def test_wide_mean_strips_tiles_and_oracle(dev, golden, k):
     single launch, which equals the oracle and the LDS-tile kernel it replaced (MI_MEAN_PREFIX=0)."""
     w, h = 1000, 300
     img = ops.synth(k, w, h)
-    whole = ops.mean_blur(img, k)
-    assert np.array_equal(host(whole), golden.meanblur(host(img), k))
-    with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
-        assert torch.equal(ops.mean_blur(img, k), whole)
-    halo = ops.halo_rows(_lib.FILTER_MEAN, k)
-    for y0, y1 in ((0, 100), (100, 117), (117, 300)):
-        r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
-        out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
-        ops.filter_strip(_lib.FILTER_MEAN, img[r0:r1], out, w, h, r0, y0, y1, k, 0.0)
-        assert torch.equal(out, whole[y0:y1]), (y0, y1)
+    # (the matrix-core kernels take these sizes by default since round 3: MI_MEAN_MFMA=0 brings the march back)
+    with ops.tuning(MI_MEAN_MFMA=0, restore={"MI_MEAN_MFMA": 11}):
+        whole = ops.mean_blur(img, k)
+        assert np.array_equal(host(whole), golden.meanblur(host(img), k))
+        with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
+            assert torch.equal(ops.mean_blur(img, k), whole)
+        halo = ops.halo_rows(_lib.FILTER_MEAN, k)
+        for y0, y1 in ((0, 100), (100, 117), (117, 300)):
+            r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+            out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+            ops.filter_strip(_lib.FILTER_MEAN, img[r0:r1], out, w, h, r0, y0, y1, k, 0.0)
+            assert torch.equal(out, whole[y0:y1]), (y0, y1)
+    assert torch.equal(ops.mean_blur(img, k), whole)          # the default path: same bytes
 
 
 def test_strips_of_images_narrower_than_the_radius(dev, golden):
@@ -460,9 +464,12 @@ def test_wide_mean_odd_shapes_equal_the_tile_kernel(dev):
     for (w, h, b) in ((32768, 256, 1), (8190, 1031, 1), (1000, 700, 3), (224, 40, 1), (225, 40, 2), (4, 4, 1), (3, 3, 1)):
         img = ops.synth(7, w, h, batch=b) if b > 1 else ops.synth(7, w, h)
         for k in (17, 31):
-            got = ops.mean_blur(img, k)
-            with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
-                assert torch.equal(got, ops.mean_blur(img, k)), (w, h, b, k)
+            default = ops.mean_blur(img, k)
+            with ops.tuning(MI_MEAN_MFMA=0, restore={"MI_MEAN_MFMA": 11}):
+                got = ops.mean_blur(img, k)
+                with ops.tuning(MI_MEAN_PREFIX=0, restore={"MI_MEAN_PREFIX": 1}):
+                    assert torch.equal(got, ops.mean_blur(img, k)), (w, h, b, k)
+            assert torch.equal(default, got), (w, h, b, k)     # the matrix-core kernels where they apply
 
 
 def test_large_batch_properties(dev):
@@ -688,21 +695,31 @@ def test_device_tier_runs_under_graph_capture(dev):
 
 @pytest.mark.parametrize("k,sigma", [(17, 3.0), (21, 4.0), (25, 2.0), (31, 6.0)])
 def test_gaussian_sizes_above_15_are_bit_exact(dev, golden, k, sigma):
-    """The reference takes any odd kernel size (imageTools.cu:478-502): 17..31 run the reference-order
-    k x k sum from LDS tiles whichever mode is asked for, bit-exact against the oracle, odd widths and
-    strips included."""
+    """The reference takes any odd kernel size (imageTools.cu:478-502): 17..31 in the direct mode run the
+    reference-order k x k sum from LDS tiles, bit-exact against the oracle, odd widths and strips included.  The
+    separable mode answers with the same kernels where the matrix-core ones do not apply (odd widths, or
+    MI_GAUSS_MFMA_MAX=15 -- round 2's behaviour) and within one level where they do."""
     for w, h in ((197, 83), (256, 64)):
         img = S.synth_image(k, w, h)
         want = golden.gaussian(img, k, sigma)
         d = torch.from_numpy(img).to(dev)
         assert np.array_equal(ops.gaussian_blur(d, k, sigma, direct=True).cpu().numpy(), want)
-        assert np.array_equal(ops.gaussian_blur(d, k, sigma).cpu().numpy(), want)
+        sep = ops.gaussian_blur(d, k, sigma).cpu().numpy()
+        if w % 4:
+            assert np.array_equal(sep, want)
+        else:
+            assert np.abs(sep.astype(np.int16) - want.astype(np.int16)).max() <= GAUSS_TOL
+        with ops.tuning(MI_GAUSS_MFMA_MAX=15):
+            assert np.array_equal(ops.gaussian_blur(d, k, sigma).cpu().numpy(), want)
     halo = ops.halo_rows(_lib.FILTER_GAUSSIAN, k)
     assert halo == k // 2 + 1
     y0, y1 = 20, 47
     lo, hi = max(0, y0 - halo), min(h, y1 + halo)
     out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
-    ops.filter_strip(_lib.FILTER_GAUSSIAN, d[lo:hi].contiguous(), out, w, h, lo, y0, y1, k, sigma)
+    with ops.tuning(MI_GAUSS_MFMA_MAX=15):
+        ops.filter_strip(_lib.FILTER_GAUSSIAN, d[lo:hi].contiguous(), out, w, h, lo, y0, y1, k, sigma)
+    assert np.array_equal(out.cpu().numpy(), want[y0:y1])
+    ops.filter_strip(_lib.FILTER_GAUSSIAN_DIRECT, d[lo:hi].contiguous(), out, w, h, lo, y0, y1, k, sigma)
     assert np.array_equal(out.cpu().numpy(), want[y0:y1])
 
 
@@ -747,6 +764,55 @@ def test_wide_gaussians_stay_within_one_level(dev, golden, k):
                     out = ops.gaussian_blur(const, k, sigma)
                     inner = out[r + 1:h - r - 1, r:w - r, :3]
                     assert int(inner.min()) == v and int(inner.max()) == v, (k, sigma, v, knobs)
+
+
+@pytest.mark.parametrize("k", [17, 19, 21, 23, 25, 27, 29, 31])
+def test_separable_gaussians_up_to_31_stay_within_one_level(dev, golden, k):
+    """MI_FILTER_GAUSSIAN for 17x17 (gauss_mfma_kernel) and 19x19 .. 31x31 (gauss_mfma_wide_kernel: aligned 16-pixel
+    halves and 16-row blocks, three K = 16 products per pass and part): within one level of the oracle's direct sum for
+    narrow to very wide sigmas, constants exact, independent of band height, strips and batch position; with
+    MI_GAUSS_MFMA_MAX=15, or for an image the matrix-core kernels do not take (width not a multiple of 4), the direct
+    kernel answers, bit-exact."""
+    w, h = 516, 110
+    imgs = [S.synth_image(k, w, h), S.pattern_image("natural", w, h, k)]
+    for sigma in (0.3, 2.5, 6.0, 40.0):
+        for img in imgs:
+            want = golden.gaussian(img, k, sigma, threads=8)
+            d = torch.from_numpy(img).to(dev)
+            got = ops.gaussian_blur(d, k, sigma).cpu().numpy()
+            assert np.abs(got.astype(np.int16) - want.astype(np.int16)).max() <= GAUSS_TOL, (k, sigma)
+            if sigma == 6.0:
+                assert (got != want).mean() < 0.02, (k, sigma)
+                with ops.tuning(MI_GAUSS_MFMA_MAX=15, restore={"MI_GAUSS_MFMA_MAX": 31}):
+                    assert np.array_equal(ops.gaussian_blur(d, k, sigma).cpu().numpy(), want), (k, sigma)
+    r = k // 2
+    for v in (0, 1, 77, 128, 254, 255):
+        const = torch.full((h, w, 4), v, dtype=torch.uint8, device=dev)
+        for sigma in (2.0, 0.7, 20.0):
+            out = ops.gaussian_blur(const, k, sigma)
+            inner = out[r + 1:h - r - 1, r:w - r, :3]
+            assert int(inner.min()) == v and int(inner.max()) == v, (k, sigma, v)
+    odd = S.synth_image(5, 131, 90)
+    assert np.array_equal(ops.gaussian_blur(torch.from_numpy(odd).to(dev), k, 3.0).cpu().numpy(), golden.gaussian(odd, k, 3.0, threads=8))
+    w, h = 1000, 203
+    img = S.synth_image(31, w, h)
+    d = torch.from_numpy(img).to(dev)
+    ref = ops.gaussian_blur(d, k, 4.0)
+    for rpb in (1, 16, 40, 96, 512):
+        with ops.tuning(MI_ROWS_PER_BAND=rpb):
+            assert torch.equal(ops.gaussian_blur(d, k, 4.0), ref), (k, rpb)
+    halo = ops.halo_rows(_lib.FILTER_GAUSSIAN, k)
+    for edges in ((0, 1, 2, 9, 33, 100, 101, 203), (0, 77, 203)):
+        pieces = []
+        for y0, y1 in zip(edges[:-1], edges[1:]):
+            r0, r1 = max(0, y0 - halo), min(h, y1 + halo)
+            out = torch.empty((y1 - y0, w, 4), dtype=torch.uint8, device=dev)
+            ops.filter_strip(_lib.FILTER_GAUSSIAN, d[r0:r1].contiguous(), out, w, h, r0, y0, y1, k, 4.0)
+            pieces.append(out)
+        assert torch.equal(torch.cat(pieces), ref), (k, edges)
+    batch = torch.stack([d, torch.flip(d, dims=(0,)), d]).contiguous()
+    got = ops.gaussian_blur(batch, k, 4.0)
+    assert torch.equal(got[0], ref) and torch.equal(got[2], ref)
 
 
 def test_matrix_core_gaussian_does_not_depend_on_the_decomposition(dev, golden):

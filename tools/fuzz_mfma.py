@@ -16,7 +16,7 @@ dev = torch.device("cuda:0")
 bad = 0
 for it in range(cases):
     mean = bool(rng.integers(0, 2))
-    k = int(rng.choice([11, 13, 15, 17] if mean else [7, 9, 11, 13, 15]))
+    k = int(rng.choice([11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31] if mean else [7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31]))
     w = 4 * int(rng.integers(1, 180))
     h = int(rng.integers(3, 220))
     if k * k > w * h:
@@ -33,7 +33,7 @@ for it in range(cases):
         yy, xx = np.mgrid[0:h, 0:w]
         img = np.stack([((xx * 3 + yy * 5 + c * 40) % 256).astype(np.uint8) for c in range(4)], -1)[None].repeat(b, 0)
         img = np.ascontiguousarray(np.stack([np.roll(img[f], f, 0) for f in range(b)]))
-    sigma = float(rng.choice([0.3, 0.8, 1.5, 2.5, 4.0, 9.0]))
+    sigma = float(rng.choice([0.3, 0.8, 1.5, 2.5, 4.0, 9.0, 30.0]))
     d = torch.from_numpy(img).to(dev)
     rpb = int(rng.choice([0, 0, 16, 48, 200]))
     with ops.tuning(MI_ROWS_PER_BAND=rpb):

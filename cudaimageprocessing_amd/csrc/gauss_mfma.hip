@@ -110,6 +110,8 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     const int ob0 = gm.ob_first + j.band * gm.bpb;
     const int n = min(gm.bpb, gm.ob_first + gm.nob - ob0);
     const int ya = max(g.y_begin, 16 * ob0 + 8), yb = min(g.y_end, 16 * (ob0 + n) + 8);
+    // (odd bands walking upwards, as in the wide kernel below and the vector-ALU marches, measured no gain here: 0.2035
+    // against 0.2032 ms per 16 x 4K, 1.597 against 1.589 ms on 32768^2 -- with 64-row bands L2 already serves half of the overlap)
 
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * GM_BUF];
 
@@ -317,6 +319,7 @@ struct GaussMfmaWide {
     int ob_first;    // first output block of the launch: output block b holds rows 16 b .. 16 b + 15
     int nob;
     int bpb;
+    int serp;        // 1: odd bands walk upwards, so that both bands at a boundary read its rows at the same time (the second from L2)
 };
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
     const int ob0 = gm.ob_first + j.band * gm.bpb;
     const int n = min(gm.bpb, gm.ob_first + gm.nob - ob0);
     const int ya = max(g.y_begin, 16 * ob0), yb = min(g.y_end, 16 * (ob0 + n));
+    const bool rev = gm.serp && (j.band & 1);      // wave-uniform
 
     __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * GW_BUF];
 
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
     const int halo_lane = delta0 + r16 * pitch + (grp - 4) * 16;  // left: chunks -4 .. -1 of row r16; right: + 36 chunks
     auto request = [&](int s, int b) __attribute__((always_inline)) {
         unsigned char* dst = ring + b * GW_BUF;
-        const int rowoff = 16 * s * pitch;
+        const int rowoff = 16 * (rev ? n + 1 - s : s) * pitch;       // step s brings input block s of the band, or n + 1 - s
 #pragma unroll
         for (int i = 0; i < 8; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + 1024 * i), 16,
@@ -461,7 +465,9 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
                     f32x4 o3[3];
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const u32x2v blk[3] = {{w2[t][c][0], w2[t][c][1]}, {w1[t][c][0], w1[t][c][1]}, {cur[c][0], cur[c][1]}};
+                        // upper, middle, lower block in that order whichever way the band is walked: the same operations per pixel
+                        const u32x2v blk[3] = {{rev ? cur[c][0] : w2[t][c][0], rev ? cur[c][1] : w2[t][c][1]}, {w1[t][c][0], w1[t][c][1]},
+                                               {rev ? w2[t][c][0] : cur[c][0], rev ? w2[t][c][1] : cur[c][1]}};
                         f32x4 o = c2v;
                         if constexpr (MODE == 0) {
 #pragma unroll
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
             }
         }
         if (s >= 2) {
-            const int y0 = 16 * (ob0 + s - 2);
+            const int y0 = 16 * (rev ? ob0 + n + 1 - s : ob0 + s - 2);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int r = 2 * i + hi;
@@ -628,12 +634,14 @@ static int launch_mfma_wide(GaussMfmaWide& gm, hipStream_t s, const u32* in, u32
     gm.nob = ob_last - ob_first + 1;
     if (gm.nob <= 0) return 0;
     g.strips = (W + 127) / 128;
-    int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : 8;
+    // measured per 16 x 4K (tools/ab_knob.py): the mean 0.2352 ms with 128-row bands against 0.2368 with 256, the Gaussian 0.2503 against 0.2453
+    int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : (MODE == 0 ? 16 : 8);
     if (tuning().rows_per_band <= 0)
         while (bpb > 1 && (i64)g.batch * g.strips * ((gm.nob + bpb - 1) / bpb) < 4096) bpb >>= 1;
     while (bpb > 1 && (i64)(bpb + 3) * 16 * W * 4 > (1LL << 30)) bpb >>= 1;
     if ((i64)(bpb + 3) * 16 * W * 4 > (1LL << 30)) return 1;
     gm.bpb = bpb;
+    gm.serp = tuning().mfma_serpentine ? 1 : 0;
     g.rows_per_band = 16 * bpb;
     g.bands = (gm.nob + bpb - 1) / bpb;
     const i64 total = (i64)g.batch * g.bands * g.strips;

@@ -64,15 +64,21 @@ report(f"mean 7x7 ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 7, out), 
 report(f"mean 11x11, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 11, out), 20, "sizes 11..17: gauss_mfma_kernel<1>, exact")
 report(f"mean 15x15, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 15, out), 20, "sizes 11..17")
 report(f"mean 17x17, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 17, out), 20, "sizes 11..17")
-report(f"mean 19x19, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 19, out), 20, "sizes 19..31: no row window, the leaving row is read again")
-report(f"mean 31x31, prefix-sum march ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "sizes 19..31")
+report(f"mean 19x19, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 19, out), 20, "sizes 19..31: gauss_mfma_wide_kernel<1>, exact")
+report(f"mean 31x31, matrix cores ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "sizes 19..31")
+ops.set_tuning("MI_MEAN_MFMA_MAX", 17)
+report(f"mean 19x19, prefix-sum march (MI_MEAN_MFMA_MAX=17) ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 19, out), 20, "the default before the wide matrix-core kernel: no row window, the leaving row is read again")
+report(f"mean 31x31, prefix-sum march (MI_MEAN_MFMA_MAX=17) ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 20, "")
 ops.set_tuning("MI_MEAN_PREFIX", 0)
 report(f"mean 31x31, LDS tiles (round 1's kernel, MI_MEAN_PREFIX=0) ({C})", ":313-340", px, 8, lambda: ops.mean_blur(fr, 31, out), 10, "kept as a cross-check")
 ops.set_tuning("MI_MEAN_PREFIX", 1)
+ops.set_tuning("MI_MEAN_MFMA_MAX", 31)
 report(f"median 3x3 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 3, out))
 report(f"median 5x5 ({C})", "README.md:3", px, 8, lambda: ops.median_blur(fr, 5, out), 20, "VALU-bound")
-for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5)):
-    report(f"Gaussian {k}x{k} sigma {s}, separable ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out), 20)
+for k, s in ((3, 7.0), (5, 1.0), (9, 2.0), (15, 2.5), (17, 3.0), (23, 4.0), (31, 5.0)):
+    report(f"Gaussian {k}x{k} sigma {s}, separable ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out), 20,
+           "matrix cores, within one level" if k >= 7 else "")
+report(f"Gaussian 31x31, direct, LDS tiles ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 31, 5.0, out, direct=True), 3, "VALU-bound: 2883 fma per pixel; what the separable mode ran before the wide matrix-core kernel")
 for k, s in ((3, 7.0), (5, 1.0), (7, 1.5)):
     report(f"Gaussian {k}x{k}, direct = the reference's summation order, bit-exact ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, k, s, out, direct=True), 10, "VALU-bound: k*k fma per pixel and channel; 5x5 and 7x7: csrc/gauss_direct.hip")
 report(f"Gaussian 9x9, direct, LDS tiles ({C})", ":287-311", px, 8, lambda: ops.gaussian_blur(fr, 9, 2.0, out, direct=True), 10, "VALU-bound: 243 fma per pixel")

@@ -91,6 +91,9 @@ for k in (19, 23, 27, 31):
         with ops.tuning(MI_ROWS_PER_BAND=rpb):
             t = min(timed(lambda: ops.mean_blur(frames, k, out)) for _ in range(2))
         cells.append(f"rpb {rpb}: {t:.4f} ms ({B * W * H * 8 / (t * 1e-3) / 8e12:.3f})")
+    with ops.tuning(MI_MFMA_SERPENTINE=0):
+        t = min(timed(lambda: ops.mean_blur(frames, k, out)) for _ in range(2))
+    cells.append(f"all bands downwards: {t:.4f} ms")
     with ops.tuning(MI_MEAN_MFMA_MAX=17):
         t = min(timed(lambda: ops.mean_blur(frames, k, out)) for _ in range(2))
     cells.append(f"prefix march: {t:.4f} ms ({B * W * H * 8 / (t * 1e-3) / 8e12:.3f})")
@@ -101,6 +104,9 @@ for k, sigma in ((17, 3.0), (23, 4.0), (31, 5.0)):
         with ops.tuning(MI_ROWS_PER_BAND=rpb):
             t = min(timed(lambda: ops.gaussian_blur(frames, k, sigma, out)) for _ in range(2))
         cells.append(f"rpb {rpb}: {t:.4f} ms ({B * W * H * 8 / (t * 1e-3) / 8e12:.3f})")
+    with ops.tuning(MI_MFMA_SERPENTINE=0):
+        t = min(timed(lambda: ops.gaussian_blur(frames, k, sigma, out)) for _ in range(2))
+    cells.append(f"all bands downwards: {t:.4f} ms")
     with ops.tuning(MI_GAUSS_MFMA_MAX=15):
         t = timed(lambda: ops.gaussian_blur(frames, k, sigma, out), n=5)
     cells.append(f"direct: {t:.3f} ms")

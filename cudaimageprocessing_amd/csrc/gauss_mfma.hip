@@ -307,9 +307,10 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Sizes 19x19 .. 31x31 (radius 9 .. 15): the same scheme on ALIGNED 16-pixel halves and 16-row blocks.  An output tile
-// needs the halves t - 1, t, t + 1 and the blocks above, at and below it, so each pass of a tile is three
-// v_mfma_f32_16x16x16_f16 per part (a lane's 16-byte chunk IS the K = 16 operand of a channel after the two v_perm_b32;
-// the row pass's result IS the column pass's operand for that block), the window keeps the row pass of TWO earlier
+// needs the halves t - 1, t, t + 1 and the blocks above, at and below it, so each pass of a tile is three K = 16 matrix
+// instructions per part (mean) or two K = 32 ones (Gaussian): a lane's 16-byte chunk is the K = 16 operand of a channel
+// after the two v_perm_b32, two chunks side by side a K = 32 one; the row pass's result for a block is the column pass's
+// operand for that block as it stands, the window keeps the row pass of TWO earlier
 // blocks, the halo is 16 pixels on each side (two DMA instructions a block), and a band of n output blocks loads n + 2.
 struct GaussMfmaWide {
     float w[31];     // as GaussMfma
@@ -356,17 +357,44 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
     const float* tbl = reinterpret_cast<const float*>(ring);
     // operand d (0, 1, 2 = the half / block before, at, after the output's): k slot i = element 4 grp + i of it, output
     // element r16; tap index = 16 (d - 1) + 4 grp + i - r16 + R.  The same index serves rows and columns.
-    h4 brow[2][3], bcol[2][3];
+    // Gaussian: d = 0 and 1 share one K = 32 operand (k slot i < 4: d = 0, else d = 1); d = 2 is the second half of another
+    // one whose first half (d = 1 again) meets zero weights: four matrix instructions per pass instead of six.
+    // (v_mfma_f32_16x16x16_f16 takes the same 16 cycles as the K = 32 form on this part, tools/mfmabench.hip; a chain that
+    // MIXES the two forms came out wrong -- two of a lane's four results zero -- with hipcc 7.2, so it is one or the other.)
+    // Mean: three K = 16 operands.  Its vector ALUs are the busier unit, and the K = 32 form costs vector moves (the
+    // middle half / block sits in two register tuples): measured 0.2375 ms against 0.2330 per 16 x 4K, while the
+    // Gaussian gains 8 % (0.2524 -> 0.2327).
+    h8 brow01[2], bcol01[2], brow2[2], bcol2[2];
+    h4 brow[3], bcol[2][3];
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int part = 0; part < 2; part++)
+        for (int part = 0; part < 2; part++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float wt = tbl[128 * part + 32 + 16 * ((i >> 2) - 1) + 4 * grp + (i & 3) - r16 + R];
+                brow01[part][i] = (_Float16)(wt * 32768.f);
+                bcol01[part][i] = (_Float16)(wt * 512.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float wt = tbl[128 * part + 32 + 16 + 4 * grp + i - r16 + R];
+                brow2[part][i] = (_Float16)0.f;
+                bcol2[part][i] = (_Float16)0.f;
+                brow2[part][4 + i] = (_Float16)(wt * 32768.f);
+                bcol2[part][4 + i] = (_Float16)(wt * 512.f);
+            }
+        }
+    } else {
 #pragma unroll
         for (int d = 0; d < 3; d++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float wt = tbl[128 * part + 32 + 16 * (d - 1) + 4 * grp + i - r16 + R];
-                brow[part][d][i] = (MODE == 1 && part == 1) ? (_Float16)0.f : (_Float16)(wt * 32768.f);
-                bcol[part][d][i] = (_Float16)(wt * 512.f);
+                const int at = 32 + 16 * (d - 1) + 4 * grp + i - r16 + R;
+                brow[d][i] = (_Float16)(tbl[at] * 32768.f);
+                bcol[0][d][i] = (_Float16)(tbl[at] * 128.f);            // against the sums' low bytes: unit 2^-17
+                bcol[1][d][i] = (_Float16)(tbl[128 + at] * 128.f);      // against their high bytes: 256 * 128
             }
+    }
     gm_wait_lds();
 
     // ---- addressing (as gauss_mfma_kernel, with input block s of the band = rows 16 (ob0 - 1 + s) ..)
@@ -435,18 +463,19 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
                 f32x4 mid[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const h4 am = __builtin_bit_cast(h4, u32x2v{pm[c][0], pm[c][1]});
-                    const h4 a0 = __builtin_bit_cast(h4, u32x2v{p0[c][0], p0[c][1]});
-                    const h4 an = __builtin_bit_cast(h4, u32x2v{pn[c][0], pn[c][1]});
                     f32x4 m = c1v;
-                    if (MODE == 0) {
-                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(am, brow[1][0], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, brow[1][1], m, 0, 0, 0);
-                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(an, brow[1][2], m, 0, 0, 0);
+                    if constexpr (MODE == 0) {
+                        const h8 a01 = __builtin_bit_cast(h8, u32x4{pm[c][0], pm[c][1], p0[c][0], p0[c][1]});
+                        const h8 a2 = __builtin_bit_cast(h8, u32x4{p0[c][0], p0[c][1], pn[c][0], pn[c][1]});     // (the first half meets zero weights)
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, brow01[1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, brow2[1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a01, brow01[0], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, brow2[0], m, 0, 0, 0);
+                    } else {
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, u32x2v{pm[c][0], pm[c][1]}), brow[0], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, u32x2v{p0[c][0], p0[c][1]}), brow[1], m, 0, 0, 0);
+                        m = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, u32x2v{pn[c][0], pn[c][1]}), brow[2], m, 0, 0, 0);
                     }
-                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(am, brow[0][0], m, 0, 0, 0);
-                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, brow[0][1], m, 0, 0, 0);
-                    m = __builtin_amdgcn_mfma_f32_16x16x16f16(an, brow[0][2], m, 0, 0, 0);
                     mid[c] = m;
                 }
                 u32 cur[3][2];
@@ -466,19 +495,23 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         // upper, middle, lower block in that order whichever way the band is walked: the same operations per pixel
-                        const u32x2v blk[3] = {{rev ? cur[c][0] : w2[t][c][0], rev ? cur[c][1] : w2[t][c][1]}, {w1[t][c][0], w1[t][c][1]},
-                                               {rev ? w2[t][c][0] : cur[c][0], rev ? w2[t][c][1] : cur[c][1]}};
+                        const u32 up0 = rev ? cur[c][0] : w2[t][c][0], up1 = rev ? cur[c][1] : w2[t][c][1];
+                        const u32 lo0 = rev ? w2[t][c][0] : cur[c][0], lo1 = rev ? w2[t][c][1] : cur[c][1];
                         f32x4 o = c2v;
                         if constexpr (MODE == 0) {
-#pragma unroll
-                            for (int d = 0; d < 3; d++) o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, blk[d]), bcol[1][d], o, 0, 0, 0);
-#pragma unroll
-                            for (int d = 0; d < 3; d++) o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, blk[d]), bcol[0][d], o, 0, 0, 0);
+                            const u32x4 b01 = {up0, up1, w1[t][c][0], w1[t][c][1]};
+                            const u32x4 b2 = {w1[t][c][0], w1[t][c][1], lo0, lo1};     // (the middle block again, against zero weights)
+                            o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b01), bcol01[1], o, 0, 0, 0);
+                            o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b2), bcol2[1], o, 0, 0, 0);
+                            o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b01), bcol01[0], o, 0, 0, 0);
+                            o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b2), bcol2[0], o, 0, 0, 0);
                         } else {
+                            const u32x2v blk[3] = {{up0, up1}, {w1[t][c][0], w1[t][c][1]}, {lo0, lo1}};
 #pragma unroll
                             for (int d = 0; d < 3; d++) {
-                                const u32x2v ah = {(blk[d][0] >> 6) & 0x007f007fu, (blk[d][1] >> 6) & 0x007f007fu};
-                                const u32x2v al = {blk[d][0] & 0x003f003fu, blk[d][1] & 0x003f003fu};
+                                // the two exact parts of the sums (below 2^13), sum >> 8 and sum & 255: one v_perm_b32 and one v_and_b32 per pair
+                                const u32x2v ah = {__builtin_amdgcn_perm(blk[d][0], blk[d][0], 0x0c030c01u), __builtin_amdgcn_perm(blk[d][1], blk[d][1], 0x0c030c01u)};
+                                const u32x2v al = {blk[d][0] & 0x00ff00ffu, blk[d][1] & 0x00ff00ffu};
                                 o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, ah), bcol[1][d], o, 0, 0, 0);
                                 o = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, al), bcol[0][d], o, 0, 0, 0);
                             }
@@ -674,7 +707,7 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
     static std::mutex mu;
     static int state[32];            // 0 unknown, 1 verified, -1 failed
     const float kk = (float)(k * k);
-    const float unit = 1.0f / 32768.0f;      // the column pass leaves sum * 2^-15
+    const float unit = k > 17 ? 1.0f / 131072.0f : 1.0f / 32768.0f;      // the column pass leaves sum * 2^-15 (the wide kernel: 2^-17)
     const float rcp = 1.0f / (kk * unit), d = 0.5f / kk - 0.5f;
     {
         std::lock_guard<std::mutex> lock(mu);
@@ -688,9 +721,9 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
         }
         if (state[k] < 0) return 1;
     }
-    if (k > 17) {
+    if (k > 17) {     // the wide kernel splits the row sums by bytes (weights 256 and 1) and leaves sum * 2^-17
         GaussMfmaWide gw;
-        for (int t = 0; t < 31; t++) { gw.w[t] = t < k ? 1.0f : 0.f; gw.wl[t] = t < k ? 64.0f : 0.f; }
+        for (int t = 0; t < 31; t++) { gw.w[t] = t < k ? 1.0f : 0.f; gw.wl[t] = t < k ? 256.0f : 0.f; }
         gw.c1 = 16384.0f; gw.c2 = 0.f; gw.rcp = rcp; gw.d = d; gw.R = R;
         return launch_mfma_wide<1>(gw, s, in, out, g);
     }

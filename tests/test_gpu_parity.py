@@ -488,10 +488,12 @@ def test_large_batch_properties(dev):
     assert int(ops.sobel(const)[2:-2, 2:-2, 0].max()) == 0
 
 
-@pytest.mark.parametrize("filt,k,sigma", [(_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_MEDIAN, 5, 0.0)])
+@pytest.mark.parametrize("filt,k,sigma", [(_lib.FILTER_GAUSSIAN, 15, 2.5), (_lib.FILTER_MEDIAN, 5, 0.0),
+                                          (_lib.FILTER_GAUSSIAN, 31, 5.0), (_lib.FILTER_MEAN, 31, 0.0)])
 def test_config4_full_size_strips_and_sampled_oracle(dev, golden, filt, k, sigma):
     """BASELINE.json config 4 at full size on one GPU: a 32768 x 32768 image (4 GiB in, 4 GiB out,
-    flat pixel indices beyond 2^30), Gaussian 15x15 and median 5x5.  The eight 4096-row strips of
+    flat pixel indices beyond 2^30), Gaussian 15x15 and median 5x5 -- and the radius-15 matrix-core kernels
+    (Gaussian and mean 31x31).  The eight 4096-row strips of
     the multi-GPU decomposition, each filtered from its rows plus halo, must reproduce the single
     launch bit for bit; bands of rows at the top, at a strip boundary, in the upper half of the
     address range and at the bottom are checked against the oracle run on those rows alone (a row
@@ -513,7 +515,8 @@ def test_config4_full_size_strips_and_sampled_oracle(dev, golden, filt, k, sigma
     for y0, y1 in ((0, 4), (4094, 4098), (20481, 20484), (h - 4, h)):
         r0, r1 = max(0, y0 - pad), min(h, y1 + pad)
         band = host(img[r0:r1])
-        ref = golden.gaussian(band, k, sigma, threads=8) if filt == _lib.FILTER_GAUSSIAN else golden.medianblur(band, k, threads=8)
+        ref = (golden.gaussian(band, k, sigma, threads=8) if filt == _lib.FILTER_GAUSSIAN else
+               golden.meanblur(band, k, threads=8) if filt == _lib.FILTER_MEAN else golden.medianblur(band, k, threads=8))
         got = host(whole[y0:y1]).astype(np.int16)
         want = ref[y0 - r0:y1 - r0].astype(np.int16)
         if r0 > 0 and y0 - r0 < pad or r1 < h and r1 - y1 < pad:

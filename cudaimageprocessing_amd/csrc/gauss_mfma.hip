@@ -394,6 +394,12 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
                 bcol[0][d][i] = (_Float16)(tbl[at] * 128.f);            // against the sums' low bytes: unit 2^-17
                 bcol[1][d][i] = (_Float16)(tbl[128 + at] * 128.f);      // against their high bytes: 256 * 128
             }
+        // a band that walks upwards meets its blocks in the order lower, middle, upper: the mean's sums are exact in any
+        // order, so it swaps the two outer weight operands once instead of selecting registers in every tile
+        if (rev) {
+#pragma unroll
+            for (int part = 0; part < 2; part++) { const h4 x = bcol[part][0]; bcol[part][0] = bcol[part][2]; bcol[part][2] = x; }
+        }
     }
     gm_wait_lds();
 
@@ -495,10 +501,10 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         // upper, middle, lower block in that order whichever way the band is walked: the same operations per pixel
-                        const u32 up0 = rev ? cur[c][0] : w2[t][c][0], up1 = rev ? cur[c][1] : w2[t][c][1];
-                        const u32 lo0 = rev ? w2[t][c][0] : cur[c][0], lo1 = rev ? w2[t][c][1] : cur[c][1];
                         f32x4 o = c2v;
                         if constexpr (MODE == 0) {
+                            const u32 up0 = rev ? cur[c][0] : w2[t][c][0], up1 = rev ? cur[c][1] : w2[t][c][1];
+                            const u32 lo0 = rev ? w2[t][c][0] : cur[c][0], lo1 = rev ? w2[t][c][1] : cur[c][1];
                             const u32x4 b01 = {up0, up1, w1[t][c][0], w1[t][c][1]};
                             const u32x4 b2 = {w1[t][c][0], w1[t][c][1], lo0, lo1};     // (the middle block again, against zero weights)
                             o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b01), bcol01[1], o, 0, 0, 0);
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(64, 2) void gauss_mfma_wide_kernel(const u32* __res
                             o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b01), bcol01[0], o, 0, 0, 0);
                             o = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, b2), bcol2[0], o, 0, 0, 0);
                         } else {
-                            const u32x2v blk[3] = {{up0, up1}, {w1[t][c][0], w1[t][c][1]}, {lo0, lo1}};
+                            const u32x2v blk[3] = {{w2[t][c][0], w2[t][c][1]}, {w1[t][c][0], w1[t][c][1]}, {cur[c][0], cur[c][1]}};     // (see bcol)
 #pragma unroll
                             for (int d = 0; d < 3; d++) {
                                 // the two exact parts of the sums (below 2^13), sum >> 8 and sum & 255: one v_perm_b32 and one v_and_b32 per pair

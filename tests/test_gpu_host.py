@@ -63,6 +63,25 @@ def test_pipeline_equals_whole_image(dev, spec, w, h, chunk):
     assert np.array_equal(buf, want)
 
 
+@pytest.mark.parametrize("spec", ["mean:17", "mean:31,gauss:23:4.0", "gauss:31:6.0,mean:19", "median:5,mean:13"])
+@pytest.mark.parametrize("w,h,chunk", [(4, 400, 16), (4, 400, 1), (8, 300, 33), (516, 150, 40), (1000, 203, 64)])
+def test_pipeline_wide_kernels_and_narrow_images(dev, spec, w, h, chunk):
+    """Chunks of the host pipeline with the radius-9..15 matrix-core kernels in the chain, and on images narrower than
+    the radius, where a chunk needs r + ceil(r / w) rows of halo per stage (the flat-index taps reach further than
+    one row): every chunking gives the whole-image result."""
+    op_list = ops.parse_ops(spec)
+    if any(k * k > w * h for _, k, _ in op_list):
+        pytest.skip("kernel larger than the image")
+    img = S.synth_image(w + chunk, w, h)
+    want = device_chain(img, op_list, dev)
+    out = np.empty_like(img)
+    ops.run_ops(out, img, w, h, op_list, chunk_rows=chunk)
+    assert np.array_equal(out, want)
+    buf = img.copy()
+    ops.run_ops(buf, buf, w, h, op_list, chunk_rows=chunk)
+    assert np.array_equal(buf, want)
+
+
 def test_pipeline_against_oracle(dev, golden):
     w, h = 320, 200
     img = S.synth_image(3, w, h)

@@ -100,7 +100,9 @@ int mi_sobel_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, vo
 int mi_gaussian_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,
                          float sigma, int mode, void *stream);
 
-/* imageMeanBlur (imageTools.cu:313-340); the reference wrapper fixes kernel_size=3 (:806). */
+/* imageMeanBlur (imageTools.cu:313-340); the reference wrapper fixes kernel_size=3 (:806).  Any odd kernel_size up to
+ * MI_MAX_KERNEL_SIZE_ANY, bit-exact (integer sums, exact division) whichever kernel runs: sizes 11..31 on aligned images
+ * take the matrix cores (csrc/gauss_mfma.hip), the others the vector ALUs. */
 int mi_meanblur_u8x4_dev(const void *d_in, void *d_out, int w, int h, int batch, int kernel_size,
                          void *stream);
 

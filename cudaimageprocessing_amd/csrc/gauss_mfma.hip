@@ -70,7 +70,7 @@ struct GaussMfma {
 #define MI_GM_BIAS (1.0 / 256.0)   // added before the truncating store: covers fp32 accumulation error, so that a constant image stays constant
 #endif
 
-constexpr int GM_MAIN = 16 * 512;          // 16 rows x 128 pixels
+[[maybe_unused]] constexpr int GM_MAIN = 16 * 512;          // 16 rows x 128 pixels
 #define GM_BUF (GM_MAIN + 1024)            // + 16 rows x (8 pixels left, 8 pixels right)
 
 template <int N>

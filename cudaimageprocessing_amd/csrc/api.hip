@@ -42,7 +42,7 @@ const Knob KNOBS[] = {
     {"MI_FFT_GROUP_MIB", &Tuning::fft_group_mib}, {"MI_FFT_SPLIT", &Tuning::fft_split}, {"MI_FFT_TWOPASS", &Tuning::fft_twopass}, {"MI_FFT_TWOPASS_REMAP", &Tuning::fft_twopass_remap}, {"MI_FFT_TWOPASS_GROUP", &Tuning::fft_twopass_group}, {"MI_FFT_FUSED_SPECTRAL", &Tuning::fft_fused_spectral},
     {"MI_FFT_CHIRPZ_BLOCKS_PER_CU", &Tuning::fft_chirpz_blocks_per_cu},
     {"MI_FFT_FUSED_CHIRPZ", &Tuning::fft_fused_chirpz}, {"MI_CHAIN_LDS_PAD_KIB", &Tuning::chain_lds_pad_kib}, {"MI_LDS_PAD_KIB", &Tuning::lds_pad_kib}, {"MI_SEP_LDS_PAD_KIB", &Tuning::sep_lds_pad_kib},
-    {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_GAUSS_MFMA", &Tuning::gauss_mfma}, {"MI_GAUSS_MFMA_MAX", &Tuning::gauss_mfma_max}, {"MI_MEAN_MFMA", &Tuning::mean_mfma}, {"MI_MFMA_SERPENTINE", &Tuning::mfma_serpentine}, {"MI_MEAN_MFMA_MAX", &Tuning::mean_mfma_max}, {"MI_GAUSS_DIRECT_WIN", &Tuning::gauss_direct_win}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
+    {"MI_PNG_ZLIB", &Tuning::png_zlib}, {"MI_GAUSS_WIDE", &Tuning::gauss_wide}, {"MI_GAUSS_MFMA", &Tuning::gauss_mfma}, {"MI_GAUSS_MFMA_MAX", &Tuning::gauss_mfma_max}, {"MI_MEAN_MFMA", &Tuning::mean_mfma}, {"MI_MFMA_SERPENTINE", &Tuning::mfma_serpentine}, {"MI_GM_STRIP", &Tuning::gm_strip}, {"MI_MEAN_MFMA_MAX", &Tuning::mean_mfma_max}, {"MI_GAUSS_DIRECT_WIN", &Tuning::gauss_direct_win}, {"MI_MEAN_PREFIX", &Tuning::mean_prefix}, {"MI_HOST_COPY_THREADS", &Tuning::host_copy_threads},
 };
 Tuning& tuning_rw()
 {

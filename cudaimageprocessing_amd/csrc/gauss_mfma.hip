@@ -95,8 +95,10 @@ static MI_DEV void gm_wait_lds()
 // subnormals again); every partial sum is an integer multiple of the unit below 2^24 units, hence exact whatever the
 // order inside the MFMA; the integer division by k^2 is one fused multiply-add and the rounding of v_cvt_pk_u8_f32,
 // verified for every reachable sum on the host.  Table part 0 = 1.0 in the window, part 1 = 64.0.
-template <int MODE>
-__global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
+// NT: tiles per strip.  8 = 128-pixel strips (512-byte row segments, 18 KiB of LDS and 214 registers a wave: two waves per
+// SIMD); 4 = 64-pixel strips (256-byte segments, 10 KiB, three waves per SIMD; MI_GM_STRIP=64).
+template <int MODE, int NT>
+__global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : 3) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
                                                                       const Geo g, const GaussMfma gm)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -104,8 +106,13 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     if (!j.valid) return;
     const int lane = j.lane, r16 = lane & 15, grp = lane >> 4;
     const int R = gm.R, W = g.W, pitch = W * 4;
-    const int cx0 = j.strip * 128;
-    const int ntile = min(8, (W - cx0 + 15) >> 4);
+    constexpr int SL = 4 * NT;            // 16-byte chunks (LDS slots) per row of the strip
+    constexpr int ROWB = 16 * SL;         // bytes per row of the strip
+    constexpr int RPI = 64 / SL;          // rows one DMA or store instruction covers
+    constexpr int NI = 16 / RPI;          // such instructions per 16-row block
+    constexpr int MAIN = 16 * ROWB, BUF = MAIN + 1024;
+    const int cx0 = j.strip * (16 * NT);
+    const int ntile = min(NT, (W - cx0 + 15) >> 4);
     // this band's output blocks [ob0, ob0 + n) and output rows [ya, yb)
     const int ob0 = gm.ob_first + j.band * gm.bpb;
     const int n = min(gm.bpb, gm.ob_first + gm.nob - ob0);
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     // (odd bands walking upwards, as in the wide kernel below and the vector-ALU marches, measured no gain here: 0.2035
     // against 0.2032 ms per 16 x 4K, 1.597 against 1.589 ms on 32768^2 -- with 64-row bands L2 already serves half of the overlap)
 
-    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * GM_BUF];
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[2 * BUF];
 
     // ---- Toeplitz operands, built once per wave from a zero-padded weight table in LDS: tbl[24 + t] = w[t]
     {
@@ -150,22 +157,22 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     bytes = bytes < 0 ? 0 : (bytes > 0x7FFFFF00LL ? 0x7FFFFF00LL : bytes);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (base - g.in_origin)), 0, (int)bytes, 0x00020000);
     const int delta0 = (int)((fmin + 8 - base) * 4);             // byte offset of (row 16 ob0, pixel cx0)
-    // main rows: DMA instruction i brings rows 2i, 2i + 1 of the block; lane -> (row 2i + hi, slot), chunk (slot - row) % 32
-    const int hi = lane >> 5, slot = lane & 31;
-    const int c0 = (slot - hi) & 31;
+    // main rows: DMA instruction i brings rows RPI i .. of the block; lane -> (row RPI i + hi, slot), chunk (slot - row) % SL
+    const int hi = lane / SL, slot = lane % SL;
+    const int c0 = (slot - hi) & (SL - 1);
     const int main_lane = delta0 + hi * pitch;
-    // halo: lane -> (group q = lane / 16, row r16); groups 0, 1 = chunks -2, -1; groups 2, 3 = chunks 32, 33
-    const int halo_lane = delta0 + r16 * pitch + (grp < 2 ? grp - 2 : 30 + grp) * 16;
+    // halo: lane -> (group q = lane / 16, row r16); groups 0, 1 = chunks -2, -1; groups 2, 3 = chunks SL, SL + 1
+    const int halo_lane = delta0 + r16 * pitch + (grp < 2 ? grp - 2 : SL - 2 + grp) * 16;
     auto request = [&](int s, int b) __attribute__((always_inline)) {     // block s of the band -> buffer b
         if (MI_GM_DBG == 2 || MI_GM_DBG == 3 || (MI_GM_DBG == 6 && s == 0)) return;
-        unsigned char* dst = ring + b * GM_BUF;
+        unsigned char* dst = ring + b * BUF;
         const int rowoff = 16 * s * pitch;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < NI; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + 1024 * i), 16,
-                                                     main_lane + rowoff + 2 * i * pitch + (((c0 - 2 * i) & 31) << 4), 0, 0, 0);
+                                                     main_lane + rowoff + RPI * i * pitch + (((c0 - RPI * i) & (SL - 1)) << 4), 0, 0, 0);
         if (MI_GM_DBG != 5 && MI_GM_DBG != 6)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + GM_MAIN), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(dst + MAIN), 16,
                                                  halo_lane + rowoff, 0, 0, 0);
     };
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((i64)ya * W - g.out_origin)), 0,
@@ -175,13 +182,13 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
     const bool st_first = st_px == 0, st_last = st_px + 4 == W;
 
     // LDS byte offsets (within a buffer) of this lane's operand chunks: half j = pixels 16 j - 8 .. 16 j + 7, chunk 4 j - 2 + grp
-    const int kap = (grp - 2 + r16) & 31;
-    const int halo_at = GM_MAIN + ((16 * grp + r16) << 4);
-    const int rd_row = r16 * 512;
-    const int wr_kap = (grp + r16) & 31;
+    const int kap = (grp - 2 + r16) & (SL - 1);
+    const int halo_at = MAIN + ((16 * grp + r16) << 4);
+    const int rd_row = r16 * ROWB;
+    const int wr_kap = (grp + r16) & (SL - 1);
 
     const f32x4 c1v = {gm.c1, gm.c1, gm.c1, gm.c1}, c2v = {gm.c2, gm.c2, gm.c2, gm.c2};
-    u32 win[8][3][2];          // the row pass of the upper block, per tile and channel: rows 4 grp .. + 3 (see `cur` below)
+    u32 win[NT][3][2];          // the row pass of the upper block, per tile and channel: rows 4 grp .. + 3 (see `cur` below)
 
     request(0, 0);
     request(1, 1);
@@ -189,18 +196,18 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
         const int b = s & 1;
         if (MI_GM_DBG == 2 || MI_GM_DBG == 3) {}
         else if (MI_GM_DBG == 6) { if (s >= 1) gm_wait_vm<0>(); }
-        else if (MI_GM_DBG == 5) { if (s + 1 <= n) { if (s <= 1) gm_wait_vm<8>(); else gm_wait_vm<16>(); } else gm_wait_vm<0>(); }
-        else if (s + 1 <= n) { if (s <= 1 || MI_GM_DBG == 1) gm_wait_vm<9>(); else gm_wait_vm<17>(); }
+        else if (MI_GM_DBG == 5) { if (s + 1 <= n) { if (s <= 1) gm_wait_vm<NI>(); else gm_wait_vm<2 * NI>(); } else gm_wait_vm<0>(); }
+        else if (s + 1 <= n) { if (s <= 1 || MI_GM_DBG == 1) gm_wait_vm<NI + 1>(); else gm_wait_vm<2 * NI + 1>(); }
         else gm_wait_vm<0>();
-        unsigned char* buf = ring + b * GM_BUF;
+        unsigned char* buf = ring + b * BUF;
         const bool prime = s == 0;
 
-        u32x4 raw[9];          // this lane's chunk of half h = pixels 16 h - 8 .. 16 h + 7 of the block's 16 rows
+        u32x4 raw[NT + 1];          // this lane's chunk of half h = pixels 16 h - 8 .. 16 h + 7 of the block's 16 rows
 #pragma unroll
-        for (int h = 0; h < 9; h++) {
-            int at = rd_row + (((kap + 4 * h) & 31) << 4);
+        for (int h = 0; h <= NT; h++) {
+            int at = rd_row + (((kap + 4 * h) & (SL - 1)) << 4);
             if (h == 0) at = grp < 2 ? halo_at : at;
-            if (h == 8) at = grp < 2 ? at : halo_at;
+            if (h == NT) at = grp < 2 ? at : halo_at;
             raw[h] = *reinterpret_cast<const u32x4*>(buf + at);
         }
         // a half's pixels as f16 pairs per channel, (pixel 0, pixel 1) and (pixel 2, pixel 3): bytes (b0, 0, b1, 0)
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
         };
         pairs(raw[0], aP);
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
+        for (int t = 0; t < NT; t++) {
             if (t < ntile && MI_GM_DBG < 4) {
                 u32 nP[3][2];
                 pairs(raw[t + 1], nP);
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                         o[i] = v;
                     }
                     // output row r16 of the block, pixels 16 t + 4 grp .. + 3: chunk 4 t + grp, slot (chunk + row) % 32
-                    *reinterpret_cast<u32x4*>(buf + rd_row + (((wr_kap + 4 * t) & 31) << 4)) = o;
+                    *reinterpret_cast<u32x4*>(buf + rd_row + (((wr_kap + 4 * t) & (SL - 1)) << 4)) = o;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; c++) { win[t][c][0] = cur[c][0]; win[t][c][1] = cur[c][1]; }
@@ -286,9 +293,9 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
             // the block's 16 output rows, 16 ob + 8 + r for output block ob = ob0 + s - 1, as dense row segments
             const int y0 = 16 * (ob0 + s - 1) + 8;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int r = 2 * i + hi;
-                u32x4 v = *reinterpret_cast<const u32x4*>(buf + r * 512 + (((slot + r) & 31) << 4));
+            for (int i = 0; i < NI; i++) {
+                const int r = RPI * i + hi;
+                u32x4 v = *reinterpret_cast<const u32x4*>(buf + r * ROWB + (((slot + r) & (SL - 1)) << 4));
                 const int y = y0 + r;
                 const bool rowok = y >= 1 && y <= g.H - 2;
                 v.x = (rowok && !st_first) ? v.x : 0u;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(64, MI_GM_WAVES) void gauss_mfma_kernel(const u32* 
                 v.z = rowok ? v.z : 0u;
                 v.w = (rowok && !st_last) ? v.w : 0u;
                 if (MI_GM_DBG == 1 || MI_GM_DBG == 3) { if (v.x == 0x12345678u && v.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane, 0, 2); }
-                else __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + 2 * i - ya) * pitch, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_lane + (y0 + RPI * i - ya) * pitch, 0, 2);
             }
         }
         gm_wait_lds();      // every read of this buffer has returned before the DMA may overwrite it
@@ -645,7 +652,8 @@ static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Ge
     gm.ob_first = ob_first;
     gm.nob = ob_last - ob_first + 1;
     if (gm.nob <= 0) return 0;
-    g.strips = (W + 127) / 128;
+    const bool narrow = tuning().gm_strip == 64;
+    g.strips = narrow ? (W + 63) / 64 : (W + 127) / 128;
     int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : 4;   // 64-row bands measured best (16 x 4K and 32768^2)
     if (tuning().rows_per_band <= 0)
         while (bpb > 1 && (i64)g.batch * g.strips * ((gm.nob + bpb - 1) / bpb) < 4096) bpb >>= 1;
@@ -659,7 +667,8 @@ static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Ge
     if (total > 0x7fffffff) return fail(MI_ERR_UNSUPPORTED, "launch too large (%lld waves)", (long long)total);
     g.total_waves = (int)total;
     g.xcd_remap = 1;
-    gauss_mfma_kernel<MODE><<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    if (narrow) gauss_mfma_kernel<MODE, 4><<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    else gauss_mfma_kernel<MODE, 8><<<(int)total, 64, 0, s>>>(in, out, g, gm);
     return hip_status(hipGetLastError(), "matrix-core filter kernel launch");
 }
 

@@ -64,6 +64,19 @@ CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_d
 CASES += [(f"gausswide{k}", _gauss_wide(k)) for k in (7, 11, 15)]
 CASES += [(f"mean{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, k, None))(k)) for k in (19, 31)]
 CASES += [(f"gauss{k}", (lambda k: lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, k, 0.2 * k, 0, None))(k)) for k in (17, 23, 31)]
+def _strip64(fn):
+    """the radius-8 matrix-core kernel on 64-pixel strips (its other instantiation, with its own counted waits)"""
+    def call(L, i, o, w, h, b):
+        assert L.mi_debug_set_tuning(b"MI_GM_STRIP", 64) == 0
+        try:
+            return fn(L, i, o, w, h, b)
+        finally:
+            L.mi_debug_set_tuning(b"MI_GM_STRIP", 128)
+    return call
+
+
+CASES += [("gauss15strip64", _strip64(lambda L, i, o, w, h, b: L.mi_gaussian_u8x4_dev(i, o, w, h, b, 15, 6.0, 0, None))),
+          ("mean13strip64", _strip64(lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 13, None)))]
 CASES += [("mean17", lambda L, i, o, w, h, b: L.mi_meanblur_u8x4_dev(i, o, w, h, b, 17, None)), ("meanvalu11", _mean_valu(11)), ("meanvalu15", _mean_valu(15))]
 
 

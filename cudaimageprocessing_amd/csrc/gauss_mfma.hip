@@ -91,10 +91,11 @@ static MI_DEV void gm_wait_lds()
 // MODE 0: Gaussian.  MODE 1: mean blur (imageMeanBlur, imageTools.cu:313-340) of size 2R + 1 <= 17, EXACT: weights 1.0
 // (times 2^15), and the row-pass accumulator starts at 2^14, whose last place is the pass's unit 2^-9 -- the integer row
 // sum (<= 17 * 255) is then simply the low 16 bits of the fp32 result.  The window keeps the sums two to a register;
-// they enter the column pass as two exact parts, sum >> 6 against weights 64 and sum & 63 against weights 1 (f16
-// subnormals again); every partial sum is an integer multiple of the unit below 2^24 units, hence exact whatever the
+// they enter the column pass as two exact parts, their high bytes against weights 256 and their low bytes against weights 1
+// (f16 subnormals again; one v_perm_b32 and one v_and_b32 per register pair); every partial sum is an integer multiple of the unit below 2^24 units, hence exact whatever the
 // order inside the MFMA; the integer division by k^2 is one fused multiply-add and the rounding of v_cvt_pk_u8_f32,
-// verified for every reachable sum on the host.  Table part 0 = 1.0 in the window, part 1 = 64.0.
+// verified for every reachable sum on the host.  Table part 0 = 1.0 in the window, part 1 = 256.0; the column weights carry
+// 2^7 instead of 2^9, so the column pass leaves sum * 2^-17.
 // NT: tiles per strip.  8 = 128-pixel strips (512-byte row segments, 18 KiB of LDS and 214 registers a wave: two waves per
 // SIMD); 4 = 64-pixel strips (256-byte segments, 10 KiB, three waves per SIMD; MI_GM_STRIP=64).
 template <int MODE, int NT>
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : 3) void gauss_mfma_kern
         reinterpret_cast<float*>(ring)[64 + lane] = wlv;
     }
     const float* tbl = reinterpret_cast<const float*>(ring);
-    // part 0: the weights' leading f16, part 1: their remainder (mean: 1.0 and 64.0).  ONE row-pass operand per part, for
+    // part 0: the weights' leading f16, part 1: their remainder (mean: 1.0 and 256.0).  ONE row-pass operand per part, for
     // every channel: k slot i < 4 = pixel 4 grp + i of the tile's first half (pixels 16 t - 8 ..), i >= 4 = pixel
     // 4 grp + i - 4 of its second half; output pixel r16; tap index = input pixel - output pixel + R.  The pixel bytes
     // enter as f16 subnormals (byte * 2^-24), so these weights carry 2^15 and the column pass's 2^9.
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : 3) void gauss_mfma_kern
             const int relx = (i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4)) - 8;
             brow[part][i] = (_Float16)(tbl[64 * part + 24 + relx - r16 + R] * 32768.f);
             const int rely = i < 4 ? 4 * grp + i : 16 + 4 * grp + (i - 4);
-            b2s[part][i] = (_Float16)(tbl[64 * part + 24 + rely - 8 - r16 + R] * 512.f);
+            b2s[part][i] = (_Float16)(tbl[64 * part + 24 + rely - 8 - r16 + R] * (MODE == 0 ? 512.f : 128.f));     // (mean: unit 2^-17, so that 256 * 128 fits f16)
         }
     gm_wait_lds();       // the table has been read: the ring is free for the first rows
 
@@ -260,12 +261,12 @@ __global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : 3) void gauss_mfma_kern
                         if constexpr (MODE == 0) {
                             o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2s[1], c2v, 0, 0, 0);
                             o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a2), b2s[0], o3[c], 0, 0, 0);
-                        } else {     // the two exact parts of the sums, sum >> 6 (weights 64) and sum & 63 (weights 1), as f16 subnormals
-                            u32x4 ah, al;
+                        } else {     // the two exact parts of the sums, sum >> 8 (weights 256) and sum & 255 (weights 1), as f16 subnormals:
+                            u32x4 ah, al;     // one v_perm_b32 and one v_and_b32 per register pair
 #pragma unroll
                             for (int i = 0; i < 4; i++) {
-                                ah[i] = (a2[i] >> 6) & 0x007f007fu;
-                                al[i] = a2[i] & 0x003f003fu;
+                                ah[i] = __builtin_amdgcn_perm(a2[i], a2[i], 0x0c030c01u);
+                                al[i] = a2[i] & 0x00ff00ffu;
                             }
                             o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, ah), b2s[1], c2v, 0, 0, 0);
                             o3[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, al), b2s[0], o3[c], 0, 0, 0);
@@ -722,7 +723,7 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
     static std::mutex mu;
     static int state[32];            // 0 unknown, 1 verified, -1 failed
     const float kk = (float)(k * k);
-    const float unit = k > 17 ? 1.0f / 131072.0f : 1.0f / 32768.0f;      // the column pass leaves sum * 2^-15 (the wide kernel: 2^-17)
+    const float unit = 1.0f / 131072.0f;      // the column pass leaves sum * 2^-17
     const float rcp = 1.0f / (kk * unit), d = 0.5f / kk - 0.5f;
     {
         std::lock_guard<std::mutex> lock(mu);
@@ -736,14 +737,14 @@ int launch_mean_mfma(int k, hipStream_t s, const u32* in, u32* out, Geo g)
         }
         if (state[k] < 0) return 1;
     }
-    if (k > 17) {     // the wide kernel splits the row sums by bytes (weights 256 and 1) and leaves sum * 2^-17
+    if (k > 17) {
         GaussMfmaWide gw;
         for (int t = 0; t < 31; t++) { gw.w[t] = t < k ? 1.0f : 0.f; gw.wl[t] = t < k ? 256.0f : 0.f; }
         gw.c1 = 16384.0f; gw.c2 = 0.f; gw.rcp = rcp; gw.d = d; gw.R = R;
         return launch_mfma_wide<1>(gw, s, in, out, g);
     }
     GaussMfma gm;
-    for (int t = 0; t < 17; t++) { gm.w[t] = t < k ? 1.0f : 0.f; gm.wl[t] = t < k ? 64.0f : 0.f; }
+    for (int t = 0; t < 17; t++) { gm.w[t] = t < k ? 1.0f : 0.f; gm.wl[t] = t < k ? 256.0f : 0.f; }
     gm.c1 = 16384.0f;      // 2^14, whose last place is the row pass's unit 2^-9: the row sum is the low 16 bits of the accumulator
     gm.c2 = 0.f;
     gm.rcp = rcp; gm.d = d;

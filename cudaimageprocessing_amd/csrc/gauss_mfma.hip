@@ -97,9 +97,10 @@ static MI_DEV void gm_wait_lds()
 // verified for every reachable sum on the host.  Table part 0 = 1.0 in the window, part 1 = 256.0; the column weights carry
 // 2^7 instead of 2^9, so the column pass leaves sum * 2^-17.
 // NT: tiles per strip.  8 = 128-pixel strips (512-byte row segments, 18 KiB of LDS and 214 registers a wave: two waves per
-// SIMD); 4 = 64-pixel strips (256-byte segments, 10 KiB, three waves per SIMD; MI_GM_STRIP=64).
+// SIMD); 4 = 64-pixel strips (256-byte segments, 10 KiB, three waves per SIMD; MI_GM_STRIP=64: 4-5 % slower); 16 = 256-pixel
+// strips (1-KiB segments, 34 KiB, one wave per SIMD; MI_GM_STRIP=256: 20 % slower).  Same bytes.
 template <int MODE, int NT>
-__global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : 3) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
+__global__ __launch_bounds__(64, NT == 8 ? MI_GM_WAVES : NT == 4 ? 3 : 1) void gauss_mfma_kernel(const u32* __restrict__ in_, u32* __restrict__ out_,
                                                                       const Geo g, const GaussMfma gm)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -653,8 +654,8 @@ static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Ge
     gm.ob_first = ob_first;
     gm.nob = ob_last - ob_first + 1;
     if (gm.nob <= 0) return 0;
-    const bool narrow = tuning().gm_strip == 64;
-    g.strips = narrow ? (W + 63) / 64 : (W + 127) / 128;
+    const bool narrow = tuning().gm_strip == 64, broad = tuning().gm_strip == 256;
+    g.strips = narrow ? (W + 63) / 64 : broad ? (W + 255) / 256 : (W + 127) / 128;
     int bpb = tuning().rows_per_band > 0 ? std::max(1, tuning().rows_per_band / 16) : 4;   // 64-row bands measured best (16 x 4K and 32768^2)
     if (tuning().rows_per_band <= 0)
         while (bpb > 1 && (i64)g.batch * g.strips * ((gm.nob + bpb - 1) / bpb) < 4096) bpb >>= 1;
@@ -669,6 +670,7 @@ static int launch_mfma(GaussMfma& gm, hipStream_t s, const u32* in, u32* out, Ge
     g.total_waves = (int)total;
     g.xcd_remap = 1;
     if (narrow) gauss_mfma_kernel<MODE, 4><<<(int)total, 64, 0, s>>>(in, out, g, gm);
+    else if (broad) gauss_mfma_kernel<MODE, 16><<<(int)total, 64, 0, s>>>(in, out, g, gm);
     else gauss_mfma_kernel<MODE, 8><<<(int)total, 64, 0, s>>>(in, out, g, gm);
     return hip_status(hipGetLastError(), "matrix-core filter kernel launch");
 }

@@ -39,7 +39,7 @@ struct Tuning {
     int gauss_wide = 1;           // MI_GAUSS_WIDE: 7x7..15x15 separable Gaussians in 16-bit fixed point (0: the fp32 kernel)
     int gauss_mfma = 1;           // MI_GAUSS_MFMA: 7x7..15x15 separable Gaussians on the matrix cores (gauss_mfma.hip; 0: gauss_wide_kernel)
     int gauss_mfma_max = 31;      // MI_GAUSS_MFMA_MAX: largest separable Gaussian on the matrix cores (15: sizes 17..31 run the direct kernels, as before round 3's wide kernel)
-    int gm_strip = 128;           // MI_GM_STRIP: strip width of the radius-8 matrix-core kernel in pixels (128, or 64: three waves per SIMD; same bytes)
+    int gm_strip = 128;           // MI_GM_STRIP: strip width of the radius-8 matrix-core kernel in pixels (128; 64: three waves per SIMD, 256: one; both measured slower; same bytes)
     int mfma_serpentine = 1;      // MI_MFMA_SERPENTINE: odd bands of the matrix-core kernels walk upwards (0: every band downwards; same bytes)
     int mean_mfma = 11;           // MI_MEAN_MFMA: smallest mean-blur size that runs on the matrix cores (sizes up to 31: 11 and above gain, measured; 0: none)
     int mean_mfma_max = 31;       // MI_MEAN_MFMA_MAX: largest one (17: the sizes above run the prefix-sum march, as before the wide matrix-core kernel)

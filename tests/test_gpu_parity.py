@@ -145,8 +145,9 @@ def test_mean_on_the_matrix_cores_is_exact(dev, golden, k):
         for rpb in (1, 40, 512):
             with ops.tuning(MI_ROWS_PER_BAND=rpb):
                 assert torch.equal(ops.mean_blur(d, k), ref), (k, rpb)
-                with ops.tuning(MI_MFMA_SERPENTINE=0, MI_GM_STRIP=64):      # every band downwards, 64-pixel strips: the same bytes
-                    assert torch.equal(ops.mean_blur(d, k), ref), (k, rpb)
+                for strip in (64, 256):      # every band downwards; 64- and 256-pixel strips: the same bytes
+                    with ops.tuning(MI_MFMA_SERPENTINE=0, MI_GM_STRIP=strip):
+                        assert torch.equal(ops.mean_blur(d, k), ref), (k, rpb, strip)
         halo = ops.halo_rows(_lib.FILTER_MEAN, k)
         edges = (0, 1, 9, 33, 100, 101, 203)
         pieces = []
@@ -835,8 +836,9 @@ def test_matrix_core_gaussian_does_not_depend_on_the_decomposition(dev, golden):
         for rpb in (1, 16, 40, 96, 512):
             with ops.tuning(MI_ROWS_PER_BAND=rpb):
                 assert torch.equal(ops.gaussian_blur(d, k, sigma), ref), (k, rpb)
-                with ops.tuning(MI_GM_STRIP=64):      # 64-pixel strips (three waves per SIMD): the same bytes
-                    assert torch.equal(ops.gaussian_blur(d, k, sigma), ref), (k, rpb)
+                for strip in (64, 256):      # 64-pixel strips (three waves per SIMD), 256-pixel strips (one): the same bytes
+                    with ops.tuning(MI_GM_STRIP=strip):
+                        assert torch.equal(ops.gaussian_blur(d, k, sigma), ref), (k, rpb, strip)
         halo = ops.halo_rows(_lib.FILTER_GAUSSIAN, k)
         for edges in ((0, 1, 2, 9, 33, 100, 101, 203), (0, 77, 203)):
             pieces = []

@@ -38,7 +38,7 @@ if os.path.exists(v):
         if not m:
             continue
         name = m.group(1)
-        key = {"chain_kernel<1, 2>": "chain_kernel", "gauss_sep_kernel<2, 1>": "gauss_sep_kernel<2>", "gauss_wide_kernel<7, 1>": "gauss_wide_kernel<7>", "gauss_mfma_kernel<0>": "gauss_mfma_kernel", "gauss_mfma_kernel<1>": "gauss_mfma_kernel<1>", "gauss_mfma_wide_kernel<0>": "gauss_mfma_wide_kernel<0>", "gauss_mfma_wide_kernel<1>": "gauss_mfma_wide_kernel<1>",
+        key = {"chain_kernel<1, 2>": "chain_kernel", "gauss_sep_kernel<2, 1>": "gauss_sep_kernel<2>", "gauss_wide_kernel<7, 1>": "gauss_wide_kernel<7>", "gauss_mfma_kernel<0>": "gauss_mfma_kernel", "gauss_mfma_kernel<1>": "gauss_mfma_kernel<1>", "gauss_mfma_kernel<0, 8>": "gauss_mfma_kernel", "gauss_mfma_kernel<1, 8>": "gauss_mfma_kernel<1>", "gauss_mfma_wide_kernel<0>": "gauss_mfma_wide_kernel<0>", "gauss_mfma_wide_kernel<1>": "gauss_mfma_wide_kernel<1>",
                "gray_kernel<3, 1>": "gray_kernel", "median3_kernel<1>": "median3_kernel", "median5_kernel<1>": "median5_kernel",
                "sobel_kernel<1>": "sobel_kernel"}.get(name)
         if key:

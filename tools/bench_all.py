@@ -113,6 +113,9 @@ big = ops.synth(4, W4, H4)
 bout = torch.empty_like(big)
 px4 = W4 * H4
 report("Gaussian 15x15 sigma 2.5 (32768x32768)", ":287-311", px4, 8, lambda: ops.gaussian_blur(big, 15, 2.5, bout), 5)
+report("Gaussian 31x31 sigma 5, separable (32768x32768)", ":287-311", px4, 8, lambda: ops.gaussian_blur(big, 31, 5.0, bout), 5, "matrix cores (radius 9..15 kernel)")
+report("mean 31x31 (32768x32768)", ":313-340", px4, 8, lambda: ops.mean_blur(big, 31, bout), 5, "matrix cores (radius 9..15 kernel), exact")
+report("mean 15x15 (32768x32768)", ":313-340", px4, 8, lambda: ops.mean_blur(big, 15, bout), 5, "matrix cores, exact")
 report("median 5x5 (32768x32768)", "README.md:3", px4, 8, lambda: ops.median_blur(big, 5, bout), 5)
 report("Sobel (32768x32768)", ":255-285", px4, 8, lambda: ops.sobel(big, bout), 5)
 report("grayscale (32768x32768)", ":217-231", px4, 8, lambda: ops.grayscale(big, bout), 5)
